@@ -1,0 +1,245 @@
+/*
+ * rtmi.h — C ABI of the MI355X path-tracing library (librtmi.so).
+ *
+ * The library replaces exactly one thing in VoidRune/Raytracer: the compute dispatch of
+ * VulkanRaytracer/res/Shaders/Raytracing.comp together with the buffers bound to it
+ * (descriptor set bindings 0..5, main.cpp:89-96, 201-208, dispatch at main.cpp:374-376).
+ * Scene records and the per-frame uniform block keep the reference's byte layouts so a caller can
+ * hand over the very arrays it would have memcpy'd into Vulkan buffers.
+ *
+ * Conventions: every function returns 0 on success or a negative rtmi_status; nothing throws
+ * across this boundary; a context is driven from one thread at a time (the reference has a single
+ * render thread and fully serialised frames, Renderer.cpp:20-21, 66-71); separate contexts, e.g.
+ * one per GPU, are independent.  Inputs are copied during the call, outputs are copied into
+ * caller-provided buffers.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RTMI_API __attribute__((visibility("default")))
+#else
+#define RTMI_API
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Records.  Layouts are those of RayTracingStructs.h:4-60 / the std140 blocks of
+ * Raytracing.comp:3-72 (sizes 260 / 32 / 48 / 80 / 96 bytes).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rtmi_frame_data {
+    float    camera_inverse_projection[16]; /* column-major                    (RT.comp:5)  */
+    float    camera_inverse_view[16];       /*                                 (RT.comp:6)  */
+    float    camera_pos[4];                 /*                                 (RT.comp:7)  */
+    float    camera_direction[4];           /* carried, never read by the path (RT.comp:8)  */
+    float    window[2];                     /* width, height as floats         (RT.comp:9)  */
+    uint32_t rays_per_pixel;                /*                                 (RT.comp:11) */
+    uint32_t max_bounce_limit;              /* "maxBouceLimit"                 (RT.comp:12) */
+    float    sky_color_horizon[4];
+    float    sky_color_zenith[4];
+    float    sun_light_direction[4];        /* used swizzled .xzy              (RT.comp:394) */
+    float    ground_color[4];
+    float    sun_focus;
+    float    sun_intensity;
+    uint32_t frame_index;                   /* 1 = overwrite the accumulation  (RT.comp:473) */
+    uint32_t sphere_number;
+    uint32_t mesh_number;
+} rtmi_frame_data;
+
+typedef struct rtmi_material {
+    float color[3];
+    float light;
+    float smoothness;
+    float pad1, pad2, pad3;
+} rtmi_material;
+
+typedef struct rtmi_sphere {
+    float center[3];
+    float radius;
+    rtmi_material material;
+} rtmi_sphere;
+
+typedef struct rtmi_mesh {
+    int32_t start_triangle;
+    int32_t num_triangles;
+    float   pad1, pad2;
+    float   bounding_point1[4];   /* box minimum */
+    float   bounding_point2[4];   /* box maximum */
+    rtmi_material material;
+} rtmi_mesh;
+
+typedef struct rtmi_triangle {
+    float p1[4], p2[4], p3[4];
+    float n1[4], n2[4], n3[4];
+} rtmi_triangle;
+
+typedef struct rtmi_ctx rtmi_ctx;
+
+typedef enum rtmi_status {
+    RTMI_OK = 0,
+    RTMI_ERR_INVALID_ARGUMENT = -1,
+    RTMI_ERR_NO_DEVICE = -2,       /* no usable HIP device / kernels not loadable */
+    RTMI_ERR_HIP = -3,             /* a HIP runtime call failed, see rtmi_last_error */
+    RTMI_ERR_OUT_OF_MEMORY = -4,
+    RTMI_ERR_NO_SCENE = -5,        /* render before rtmi_upload_scene */
+    RTMI_ERR_SCENE_MISMATCH = -6,  /* frame data counts exceed the uploaded scene */
+    RTMI_ERR_IO = -7,
+    RTMI_ERR_UNSUPPORTED = -8
+} rtmi_status;
+
+/* Kernel variants.  All produce bit-identical results. */
+typedef enum rtmi_variant {
+    RTMI_VARIANT_MEGAKERNEL = 0,   /* one lane per pixel, frame / sample / bounce loops nested as in RT.comp:464-468, 413 */
+    RTMI_VARIANT_REGENERATE = 1,   /* one lane per pixel, single segment loop; a lane that ends a path starts its next one */
+    RTMI_VARIANT_WAVEFRONT  = 2    /* queued segments with ballot/prefix-sum compaction between bounces */
+} rtmi_variant;
+
+/* Event counters (uint64 each), index = rtmi_counter.  Same events the CPU oracle counts. */
+typedef enum rtmi_counter {
+    RTMI_N_SPHERE_TESTS = 0,
+    RTMI_N_SPHERE_DISC_GE0,
+    RTMI_N_SPHERE_WINS,
+    RTMI_N_BOX_TESTS,
+    RTMI_N_TRI_TESTS,
+    RTMI_N_TRI_WINS,
+    RTMI_N_HIT_BOUNCES,
+    RTMI_N_ENV_EVALS,
+    RTMI_N_PIXEL_FRAMES,
+    RTMI_N_PATHS,
+    RTMI_N_SEGMENTS,
+    RTMI_N_COUNTERS = 16
+} rtmi_counter;
+
+#define RTMI_MISS_ID 0xFFFFFFFFu
+
+/* ------------------------------------------------------------------------------------------
+ * Context.  Replaces Core/Renderer device selection + the two storage images created at
+ * main.cpp:74-82 (rgba8 output, rgba32f accumulation), both zero-initialised.
+ * ---------------------------------------------------------------------------------------- */
+RTMI_API int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out);
+RTMI_API int rtmi_destroy(rtmi_ctx *ctx);
+/* Message of the last failure on ctx (or of the last failed rtmi_create when ctx is NULL). */
+RTMI_API const char *rtmi_last_error(const rtmi_ctx *ctx);
+RTMI_API const char *rtmi_version(void);
+
+/* Replaces the three storage-buffer uploads at main.cpp:171-200 (Buffer::Map + memcpy of
+ * Sphere[], Triangle[], Mesh[]).  Takes the reference's AoS records and repacks them on the way to
+ * the device.  May be called again to change the scene (main.cpp:296-298). */
+RTMI_API int rtmi_upload_scene(rtmi_ctx *ctx,
+                               const rtmi_sphere *spheres, uint32_t n_spheres,
+                               const rtmi_triangle *triangles, uint32_t n_triangles,
+                               const rtmi_mesh *meshes, uint32_t n_meshes);
+
+/* Replaces "memcpy the uniform block + vkCmdDispatch" (main.cpp:370-376): one frame with
+ * fd->frame_index, including the in-shader overwrite when frame_index == 1 (RT.comp:473-477). */
+RTMI_API int rtmi_render(rtmi_ctx *ctx, const rtmi_frame_data *fd);
+
+/* Same result as calling rtmi_render n_frames times with frame_index = first_frame,
+ * first_frame+1, ... and otherwise unchanged *fd (fd->frame_index itself is ignored), but in one
+ * launch with the running sum kept in registers.  No counterpart call in the reference; it is the
+ * reference frame loop (main.cpp:236-444) with a static camera. */
+RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
+                                uint32_t first_frame, uint32_t n_frames);
+
+RTMI_API int rtmi_set_variant(rtmi_ctx *ctx, int variant);
+RTMI_API int rtmi_get_variant(const rtmi_ctx *ctx);
+
+/* Accumulation image (binding 5, rgba32f, running SUM not mean; RT.comp:471-479). */
+RTMI_API int rtmi_clear_accum(rtmi_ctx *ctx);
+RTMI_API int rtmi_read_accum(rtmi_ctx *ctx, float *rgba, size_t bytes);
+RTMI_API int rtmi_write_accum(rtmi_ctx *ctx, const float *rgba, size_t bytes);
+/* Display image (binding 4, rgba8: sum / frame_index of the last rendered frame; RT.comp:480). */
+RTMI_API int rtmi_read_output_rgba8(rtmi_ctx *ctx, uint8_t *rgba, size_t bytes);
+/* Recompute the display image as sum / divisor (used after summing partial images of several GPUs). */
+RTMI_API int rtmi_resolve_output(rtmi_ctx *ctx, uint32_t divisor);
+
+/* Use a caller-owned device buffer of width*height float4 as the accumulation image (for example
+ * memory that a collective library reduces in place).  NULL returns to the internal buffer.  The
+ * shader has no counterpart; in Vulkan terms this is rebinding descriptor 5. */
+RTMI_API int rtmi_bind_accum(rtmi_ctx *ctx, void *device_float4);
+RTMI_API void *rtmi_accum_device_ptr(rtmi_ctx *ctx);
+/* Launch on a caller-owned hipStream_t (NULL returns to the context's own stream). */
+RTMI_API int rtmi_set_stream(rtmi_ctx *ctx, void *hip_stream);
+RTMI_API int rtmi_synchronize(rtmi_ctx *ctx);
+/* Device time of the most recent render call, from HIP events recorded around its kernels on the
+ * stream they ran on; waits for them to complete. */
+RTMI_API int rtmi_last_render_ms(rtmi_ctx *ctx, float *ms);
+
+/* Validation outputs (the shader exports none; ids are defined as: sphere i -> i, triangle j ->
+ * sphere_number + j, miss -> RTMI_MISS_ID).  Enabling them selects instrumented kernels that also
+ * fill the event counters; results of the images are unaffected. */
+RTMI_API int rtmi_enable_validation(rtmi_ctx *ctx, int on);
+RTMI_API int rtmi_read_hit_ids(rtmi_ctx *ctx, uint32_t *ids, size_t bytes);      /* first segment of the last frame */
+RTMI_API int rtmi_read_chain_hash(rtmi_ctx *ctx, uint32_t *hash, size_t bytes);  /* hash of all segment ids of the last call */
+RTMI_API int rtmi_read_rng_state(rtmi_ctx *ctx, uint32_t *state, size_t bytes);  /* RNG state after the last frame */
+RTMI_API int rtmi_get_counters(rtmi_ctx *ctx, uint64_t *counters, size_t n);
+RTMI_API int rtmi_reset_counters(rtmi_ctx *ctx);
+
+/* Device arithmetic self-test hooks: evaluate one primitive of the arithmetic contract on the GPU
+ * for n inputs.  op: 0 1/x, 1 sqrt, 2 log2 (library polynomial), 3 exp2 (library polynomial),
+ * 4 uint32 -> float scaled by 2^-32 (input reinterpreted as uint32), 5 pow(x, y), 6 x / y. */
+RTMI_API int rtmi_selftest_math(rtmi_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Host side kept from the reference (C wrappers over the C++ classes of the same names).
+ * ---------------------------------------------------------------------------------------- */
+
+/* LoadModel of ModelLoader.h:6-11 / ModelLoader.cpp:31-142: appends the file's faces to
+ * triangles[] and one record to meshes[].  quad_rule: 0 = split a quad along its shorter diagonal,
+ * ties as (0,1,3),(1,2,3); 1 = fan (0,1,2),(0,2,3).  Returns the number of triangles appended.
+ * A file that cannot be read returns RTMI_ERR_IO and, like the reference (ModelLoader.cpp:43-45),
+ * appends nothing. */
+RTMI_API int rtmi_load_model(const char *path,
+                             rtmi_triangle *triangles, uint32_t *n_triangles, uint32_t triangle_capacity,
+                             rtmi_mesh *meshes, uint32_t *n_meshes, uint32_t mesh_capacity,
+                             const rtmi_material *material, const float translate[3], const float scale[3],
+                             int quad_rule);
+
+/* Constants of main.cpp:116-123, 151-153 (rays_per_pixel 4, max bounces 6, sky / sun / ground). */
+RTMI_API void rtmi_default_frame_data(rtmi_frame_data *fd);
+
+/* CameraFPS (CameraFPS.h:5-39, CameraFPS.cpp:5-88) without the window: input is passed in. */
+typedef struct rtmi_camera {
+    float pitch, yaw;               /* degrees; defaults 0, -90 */
+    float fov, near_plane, far_plane; /* 70 (handed to the projection as radians), 0.1, 1000 */
+    float sensitivity;              /* 0.2 */
+    int   moved;
+    float projection[16], view[16], inverse_projection[16], inverse_view[16];
+    float position[3], forward[3], up[3], right[3];
+    double last_mouse_x, last_mouse_y;
+    uint32_t width, height;
+} rtmi_camera;
+
+typedef struct rtmi_camera_input {
+    double mouse_x, mouse_y;
+    int mouse_button_2;
+    int key_w, key_s, key_a, key_d, key_space, key_left_shift, key_f, key_c;
+} rtmi_camera_input;
+
+RTMI_API void rtmi_camera_init(rtmi_camera *cam, uint32_t width, uint32_t height,
+                               double mouse_x, double mouse_y);
+/* Place the camera explicitly (no counterpart key in the reference; equals setting the public
+ * members position / yaw / pitch and recomputing as CameraFPS.cpp:48-53, 85-86 do). */
+RTMI_API void rtmi_camera_set_pose(rtmi_camera *cam, const float position[3], float yaw, float pitch);
+RTMI_API void rtmi_camera_update(rtmi_camera *cam, double delta_time, const rtmi_camera_input *in);
+/* The per-frame policy of main.cpp:355-363 and 332-335: copy the camera into fd, frame_index++,
+ * frame_index = 1 if the camera moved; reset_key (the Q key) zeroes frame_index beforehand. */
+RTMI_API void rtmi_frame_advance(rtmi_frame_data *fd, const rtmi_camera *cam, int reset_key);
+
+/* Headless replacements for presentation.  rows are written top-down for an upright picture
+ * (buffer row 0 is the bottom of the view: main.cpp:340-347).  srgb != 0 applies the
+ * linear -> sRGB encode the B8G8R8A8_SRGB swapchain performs (Swapchain.cpp:260-265). */
+RTMI_API int rtmi_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb);
+/* Mean radiance sum / frames as a little-endian PFM (3 x float32). */
+RTMI_API int rtmi_write_pfm(const char *path, const float *accum_rgba, uint32_t width, uint32_t height, uint32_t frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,147 @@
+// rt_host_c.cpp — C wrappers (rtmi.h) over the C++ host classes of rt_host.hpp.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rt_host.hpp"
+
+namespace {
+
+void CameraToC(const rtmi::CameraFPS &c, rtmi_camera *o)
+{
+    o->pitch = c.pitch;
+    o->yaw = c.yaw;
+    o->fov = c.fov;
+    o->near_plane = c.nearPlane;
+    o->far_plane = c.farPlane;
+    o->sensitivity = c.sensitivity;
+    o->moved = c.moved ? 1 : 0;
+    std::memcpy(o->projection, c.projection.data(), 64);
+    std::memcpy(o->view, c.view.data(), 64);
+    std::memcpy(o->inverse_projection, c.inverseProjection.data(), 64);
+    std::memcpy(o->inverse_view, c.inverseView.data(), 64);
+    const rtmi::Vec3 *src[4] = {&c.position, &c.forward, &c.up, &c.right};
+    float *dst[4] = {o->position, o->forward, o->up, o->right};
+    for (int i = 0; i < 4; i++) {
+        dst[i][0] = src[i]->x;
+        dst[i][1] = src[i]->y;
+        dst[i][2] = src[i]->z;
+    }
+    o->last_mouse_x = c.lastMouseX;
+    o->last_mouse_y = c.lastMouseY;
+    o->width = c.width;
+    o->height = c.height;
+}
+
+rtmi::CameraFPS CameraFromC(const rtmi_camera *i)
+{
+    rtmi::CameraFPS c(i->width, i->height, i->last_mouse_x, i->last_mouse_y);
+    c.pitch = i->pitch;
+    c.yaw = i->yaw;
+    c.fov = i->fov;
+    c.nearPlane = i->near_plane;
+    c.farPlane = i->far_plane;
+    c.sensitivity = i->sensitivity;
+    c.moved = i->moved != 0;
+    std::memcpy(c.projection.data(), i->projection, 64);
+    std::memcpy(c.view.data(), i->view, 64);
+    std::memcpy(c.inverseProjection.data(), i->inverse_projection, 64);
+    std::memcpy(c.inverseView.data(), i->inverse_view, 64);
+    c.position = {i->position[0], i->position[1], i->position[2]};
+    c.forward = {i->forward[0], i->forward[1], i->forward[2]};
+    c.up = {i->up[0], i->up[1], i->up[2]};
+    c.right = {i->right[0], i->right[1], i->right[2]};
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtmi_load_model(const char *path, rtmi_triangle *triangles, uint32_t *n_triangles, uint32_t triangle_capacity,
+                    rtmi_mesh *meshes, uint32_t *n_meshes, uint32_t mesh_capacity, const rtmi_material *material,
+                    const float translate[3], const float scale[3], int quad_rule)
+{
+    if (!path || !triangles || !n_triangles || !meshes || !n_meshes || !material || !translate || !scale)
+        return RTMI_ERR_INVALID_ARGUMENT;
+    if (quad_rule != 0 && quad_rule != 1) return RTMI_ERR_INVALID_ARGUMENT;
+    try {
+        // LoadModel records start_triangle = triangles.size(); keep the caller's count as the base
+        std::vector<rtmi::Triangle> tris(*n_triangles);
+        std::vector<rtmi::Mesh> ms;
+        if (!rtmi::LoadModel(path, tris, ms, *material, rtmi::Vec3{translate[0], translate[1], translate[2]},
+                             rtmi::Vec3{scale[0], scale[1], scale[2]}, static_cast<rtmi::QuadRule>(quad_rule)))
+            return RTMI_ERR_IO;
+        const size_t added = tris.size() - *n_triangles;
+        if (tris.size() > triangle_capacity || *n_meshes + ms.size() > mesh_capacity) return RTMI_ERR_OUT_OF_MEMORY;
+        std::memcpy(triangles + *n_triangles, tris.data() + *n_triangles, added * sizeof(rtmi_triangle));
+        for (const auto &m : ms) meshes[(*n_meshes)++] = m;
+        *n_triangles = (uint32_t)tris.size();
+        return (int)added;
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_IO;
+    }
+}
+
+void rtmi_default_frame_data(rtmi_frame_data *fd)
+{
+    if (fd) rtmi::DefaultFrameData(*fd);
+}
+
+void rtmi_camera_init(rtmi_camera *cam, uint32_t width, uint32_t height, double mouse_x, double mouse_y)
+{
+    if (!cam) return;
+    rtmi::CameraFPS c(width, height, mouse_x, mouse_y);
+    CameraToC(c, cam);
+}
+
+void rtmi_camera_set_pose(rtmi_camera *cam, const float position[3], float yaw, float pitch)
+{
+    if (!cam || !position) return;
+    rtmi::CameraFPS c = CameraFromC(cam);
+    c.SetPose(rtmi::Vec3{position[0], position[1], position[2]}, yaw, pitch);
+    CameraToC(c, cam);
+}
+
+void rtmi_camera_update(rtmi_camera *cam, double delta_time, const rtmi_camera_input *in)
+{
+    if (!cam || !in) return;
+    rtmi::CameraFPS c = CameraFromC(cam);
+    rtmi::CameraInput ci;
+    ci.mouseX = in->mouse_x;
+    ci.mouseY = in->mouse_y;
+    ci.mouseButton2 = in->mouse_button_2 != 0;
+    ci.keyW = in->key_w != 0;
+    ci.keyS = in->key_s != 0;
+    ci.keyA = in->key_a != 0;
+    ci.keyD = in->key_d != 0;
+    ci.keySpace = in->key_space != 0;
+    ci.keyLeftShift = in->key_left_shift != 0;
+    ci.keyF = in->key_f != 0;
+    ci.keyC = in->key_c != 0;
+    c.Update(delta_time, ci);
+    CameraToC(c, cam);
+}
+
+void rtmi_frame_advance(rtmi_frame_data *fd, const rtmi_camera *cam, int reset_key)
+{
+    if (!fd || !cam) return;
+    rtmi::CameraFPS c = CameraFromC(cam);
+    rtmi::FrameAdvance(*fd, c, reset_key != 0);
+}
+
+int rtmi_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb)
+{
+    if (!path || !rgba8 || !width || !height) return RTMI_ERR_INVALID_ARGUMENT;
+    return rtmi::WritePPM(path, rgba8, width, height, srgb != 0) ? RTMI_OK : RTMI_ERR_IO;
+}
+
+int rtmi_write_pfm(const char *path, const float *accum_rgba, uint32_t width, uint32_t height, uint32_t frames)
+{
+    if (!path || !accum_rgba || !width || !height) return RTMI_ERR_INVALID_ARGUMENT;
+    return rtmi::WritePFM(path, accum_rgba, width, height, frames) ? RTMI_OK : RTMI_ERR_IO;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// rt_device.hpp — device-side arithmetic and per-segment routines for gfx950 (wave64).
+//
+// Arithmetic contract ("strict"): every float operation below is one individually rounded IEEE
+// binary32 operation, in a fixed order; the translation unit is compiled with -ffp-contract=off so
+// hipcc never fuses a multiply into an add; '/' and sqrtf are correctly rounded (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt); min/max are compare+select with GLSL's operand
+// rule; pow is a fixed polynomial exp2(y*log2(x)).  Under this contract the kernels reproduce a
+// scalar CPU evaluation of the shader bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rtd {
+
+constexpr uint32_t kMissId = 0xFFFFFFFFu;
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+// GLSL min/max operand rule: min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+__device__ __forceinline__ float gmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ V3 gmix(V3 a, V3 b, float t)
+{
+    return mk(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t));
+}
+__device__ __forceinline__ V3 normalize(V3 a)
+{
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return a * inv;
+}
+__device__ __forceinline__ V3 reflect(V3 i, V3 n)
+{
+    float k = 2.0f * dot(n, i);
+    return i - n * k;
+}
+__device__ __forceinline__ float smoothstep(float e0, float e1, float x)
+{
+    float t = gclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+// ---- pow(x, y) = exp2(y * log2(x)) with fixed polynomials (coefficients: the public-domain Cephes
+// single-precision log / exp2 fits).  Step for step the same sequence as the CPU checker uses.
+__device__ __forceinline__ float log2_poly(float x)
+{
+    if (!(x == x)) return x;
+    if (x < 0.0f) return __uint_as_float(0x7FC00000u);
+    if (x == 0.0f) return __uint_as_float(0xFF800000u);
+    if (x == __uint_as_float(0x7F800000u)) return x;
+    int e = 0;
+    if (x < __uint_as_float(0x00800000u)) {
+        x = x * 16777216.0f;
+        e = -24;
+    }
+    uint32_t b = __float_as_uint(x);
+    e += (int)((b >> 23) & 0xFFu) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356237f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f + -1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f + -1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f + -1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f + -2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (p * f) * z;
+    y = y - 0.5f * z;
+    float r = y * 0.44269504088896340736f;
+    r = r + f * 0.44269504088896340736f;
+    r = r + y;
+    r = r + f;
+    r = r + (float)e;
+    return r;
+}
+
+__device__ __forceinline__ float exp2_poly(float x)
+{
+    if (!(x == x)) return x;
+    if (x > 128.0f) return __uint_as_float(0x7F800000u);
+    if (x < -150.0f) return 0.0f;
+    float fl = floorf(x);
+    int n = (int)fl;
+    float r = x - fl;
+    if (r > 0.5f) {
+        n += 1;
+        r = r - 1.0f;
+    }
+    float p = 1.535336188319500e-4f;
+    p = p * r + 1.339887440266574e-3f;
+    p = p * r + 9.618437357674640e-3f;
+    p = p * r + 5.550332471162809e-2f;
+    p = p * r + 2.402264791363012e-1f;
+    p = p * r + 6.931472028550421e-1f;
+    p = p * r + 1.0f;
+    if (n > 127) {
+        p = p * __uint_as_float(0x7F000000u);
+        n -= 127;
+    }
+    if (n < -126) {
+        p = p * __uint_as_float(0x00800000u);
+        n += 126;
+    }
+    if (n < -126) n = -126;
+    return p * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+__device__ __forceinline__ float pow_poly(float x, float y)
+{
+    if (x == 0.0f && y > 0.0f) return 0.0f;
+    return exp2_poly(y * log2_poly(x));
+}
+
+// ---- RNG (Raytracing.comp:106-112).  The shader divides by the literal 4294967295.0, which is
+// 2^32 in binary32, so the scaling is exact.
+__device__ __forceinline__ float rng_next(uint32_t &s)
+{
+    s = s * 747796405u + 2891336453u;
+    uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    r = (r >> 22) ^ r;
+    return (float)r * 2.3283064365386963e-10f;  // exact: 2^-32
+}
+
+// float -> UNORM8 of the rgba8 image: NaN -> 0, clamp, *255, round to nearest even.
+__device__ __forceinline__ uint32_t unorm8(float v)
+{
+    if (!(v == v)) return 0u;
+    float c = gclamp(v, 0.0f, 1.0f);
+    return (uint32_t)rintf(c * 255.0f);
+}
+
+// ---- device scene: uniform-indexed records are 16-byte aligned so the compiler can fetch them with
+// scalar loads (one s_load_dwordx4..x16 per record) and feed them to VALU as SGPR operands.
+struct DeviceScene {
+    const float4 *sphere_geom;  // [S]      {cx, cy, cz, r*r}
+    const float4 *tri_isect;    // [T][4]   {p1,-} {AB,-} {AC,-} {N = AB x AC,-}
+    const float4 *tri_shade;    // [T][3]   {n1,-} {n2,-} {n3,-}
+    const float4 *mesh_box;     // [M][2]   {lo.xyz, bits(start)} {hi.xyz, bits(count)}
+    const float4 *materials;    // [S + M][2] {r, g, b, light} {smoothness, 0, 0, 0}
+    uint32_t n_spheres, n_triangles, n_meshes;
+};
+
+struct Hit {
+    float t;
+    uint32_t prim;  // kMissId when nothing was hit
+    uint32_t mat;   // row of materials[]
+    float u, v;     // barycentrics of the winning triangle
+};
+
+struct Counters {
+    uint32_t c[11];
+};
+
+// ClosestHit of Raytracing.comp:338-388 with the ray-invariant terms hoisted and everything that is
+// only needed for the winner (hit point, normal, material) left to the caller.  Primitive loops are
+// wave-uniform: record fetches are scalar, lanes differ only in the ray.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes,
+                                           V3 o, V3 d, Counters &cn)
+{
+    Hit best;
+    best.t = kFltMax;
+    best.prim = kMissId;
+    best.mat = 0;
+    best.u = 0.0f;
+    best.v = 0.0f;
+
+    // RaySphere, Raytracing.comp:130-161
+    if (n_spheres > 0) {
+        const float a = dot(d, d);
+        const float a4 = 4.0f * a;
+        const float a2 = 2.0f * a;
+        for (uint32_t i = 0; i < n_spheres; i++) {
+            const float4 g = sc.sphere_geom[i];
+            V3 oc = o - mk(g.x, g.y, g.z);
+            float b = 2.0f * dot(oc, d);
+            float c = dot(oc, oc) - g.w;
+            float disc = b * b - a4 * c;
+            if (COUNT) cn.c[0]++;
+            if (disc >= 0.0f) {
+                if (COUNT) cn.c[1]++;
+                float t = (-b - sqrtf(disc)) / a2;
+                if (t > 0.0001f && t < best.t) {
+                    best.t = t;
+                    best.prim = i;
+                    best.mat = i;
+                }
+            }
+        }
+    }
+
+    // RayBox gate + RayTriangle, Raytracing.comp:352-368, 311-336, 286-309
+    if (n_meshes > 0) {
+        const float fx = 1.0f / d.x, fy = 1.0f / d.y, fz = 1.0f / d.z;
+        for (uint32_t m = 0; m < n_meshes; m++) {
+            const float4 lo = sc.mesh_box[2 * m + 0];
+            const float4 hi = sc.mesh_box[2 * m + 1];
+            float t1 = (lo.x - o.x) * fx;
+            float t2 = (hi.x - o.x) * fx;
+            float t3 = (lo.y - o.y) * fy;
+            float t4 = (hi.y - o.y) * fy;
+            float t5 = (lo.z - o.z) * fz;
+            float t6 = (hi.z - o.z) * fz;
+            float tmin = gmax(gmax(gmin(t1, t2), gmin(t3, t4)), gmin(t5, t6));
+            float tmax = gmin(gmin(gmax(t1, t2), gmax(t3, t4)), gmax(t5, t6));
+            if (COUNT) cn.c[3]++;
+            const bool inside = !(tmax < 0.0f) && !(tmin > tmax);
+            if (inside) {
+                const uint32_t start = __float_as_uint(lo.w);
+                const uint32_t count = __float_as_uint(hi.w);
+                for (uint32_t j = start; j < start + count; j++) {
+                    const float4 P = sc.tri_isect[4 * j + 0];
+                    const float4 N = sc.tri_isect[4 * j + 3];
+                    if (COUNT) cn.c[4]++;
+                    float det = -dot(d, mk(N.x, N.y, N.z));
+                    if (det >= 1e-6f) {
+                        const float4 AB = sc.tri_isect[4 * j + 1];
+                        const float4 AC = sc.tri_isect[4 * j + 2];
+                        V3 ao = o - mk(P.x, P.y, P.z);
+                        V3 dao = cross(ao, d);
+                        float inv = 1.0f / det;
+                        float t = dot(ao, mk(N.x, N.y, N.z)) * inv;
+                        float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv;
+                        float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv;
+                        float w = 1.0f - u - v;
+                        if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
+                            best.t = t;
+                            best.prim = n_spheres + j;
+                            best.mat = n_spheres + m;
+                            best.u = u;
+                            best.v = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return best;
+}
+
+// Hit point and shading normal of the winner (Raytracing.comp:150-151, 304-305), evaluated once.
+__device__ __forceinline__ void resolve_hit(const DeviceScene &sc, uint32_t n_spheres, V3 o, V3 d,
+                                            const Hit &h, V3 &pos, V3 &nrm)
+{
+    pos = o + d * h.t;
+    if (h.prim < n_spheres) {
+        const float4 g = sc.sphere_geom[h.prim];
+        nrm = normalize(pos - mk(g.x, g.y, g.z));
+    } else {
+        const uint32_t j = h.prim - n_spheres;
+        const float4 n1 = sc.tri_shade[3 * j + 0];
+        const float4 n2 = sc.tri_shade[3 * j + 1];
+        const float4 n3 = sc.tri_shade[3 * j + 2];
+        const float w = 1.0f - h.u - h.v;
+        V3 bl = mk(n1.x, n1.y, n1.z) * w + mk(n2.x, n2.y, n2.z) * h.u + mk(n3.x, n3.y, n3.z) * h.v;
+        nrm = normalize(bl);
+    }
+}
+
+struct Sky {
+    V3 horizon, zenith, ground;
+    V3 neg_sun;  // -(sunLightDirection.xzy)
+    float sun_focus, sun_intensity;
+};
+
+// GetEnvironmentLight, Raytracing.comp:390-406
+__device__ __forceinline__ V3 env_light(const Sky &sky, V3 d)
+{
+    float grad_t = pow_poly(smoothstep(0.0f, 0.4f, d.y), 0.35f);
+    V3 grad = gmix(sky.horizon, sky.zenith, grad_t);
+    float sun = pow_poly(gmax(0.0f, dot(d, sky.neg_sun)), sky.sun_focus) * sky.sun_intensity;
+    float g2s = smoothstep(-0.01f, 0.0f, d.y);
+    float mask = (g2s >= 1.0f) ? 1.0f : 0.0f;
+    V3 base = gmix(sky.ground, grad, g2s);
+    float add = sun * mask;
+    return mk(base.x + add, base.y + add, base.z + add);
+}
+
+// The hit branch of Trace, Raytracing.comp:417-431.
+__device__ __forceinline__ void bounce(const DeviceScene &sc, uint32_t n_spheres, const Hit &h,
+                                       V3 &o, V3 &d, V3 &light, V3 &thr, uint32_t &rng)
+{
+    V3 pos, nrm;
+    resolve_hit(sc, n_spheres, o, d, h, pos, nrm);
+    const float4 m0 = sc.materials[2 * h.mat + 0];
+    const float smooth = sc.materials[2 * h.mat + 1].x;
+    float rx = rng_next(rng) * 2.0f - 1.0f;
+    float ry = rng_next(rng) * 2.0f - 1.0f;
+    float rz = rng_next(rng) * 2.0f - 1.0f;
+    V3 diffuse = normalize(nrm + mk(rx, ry, rz));
+    V3 spec = reflect(d, nrm);
+    o = pos;
+    d = gmix(diffuse, spec, smooth);
+    float e = 1.0f * m0.w;
+    light = light + mk(e * thr.x, e * thr.y, e * thr.z);
+    thr = thr * mk(m0.x, m0.y, m0.z);
+}
+
+}  // namespace rtd

@@ -1,0 +1,38 @@
+// rt_kernels.hpp — launch interface between the C ABI layer and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.hpp"
+
+// Everything one dispatch needs, passed by value in the kernel argument segment (scalar loads).
+// The first block mirrors the uniform block of Raytracing.comp:3-24.
+struct RenderParams {
+    float inv_proj[16];
+    float inv_view[16];
+    float cam_pos[3];
+    float window_w, window_h;  // frameData.window as floats
+    uint32_t width, height;    // image extent guarded by the kernels
+    uint32_t rays_per_pixel, max_bounce;
+    float sky_horizon[3], sky_zenith[3], sun_dir[3], ground[3];
+    float sun_focus, sun_intensity;
+    uint32_t sphere_number, mesh_number;
+    uint32_t first_frame, n_frames;  // frame_index runs first_frame .. first_frame + n_frames - 1
+    uint32_t rpp_is_pow2;
+    float rpp_recip;
+
+    rtd::DeviceScene scene;
+
+    float4 *accum;          // [height][width] running sum, w = 1
+    uint32_t *out_rgba8;    // [height][width] packed r | g<<8 | b<<16 | a<<24
+    uint32_t *hit_ids;      // validation only
+    uint32_t *chain_hash;   // validation only
+    uint32_t *rng_state;    // validation only
+    unsigned long long *counters;  // validation only, 16 entries
+};
+
+const char *rt_kernel_name(int variant);
+hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream);
+hipError_t rt_launch_resolve(const float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
+hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);

@@ -1,0 +1,501 @@
+// rtmi_api.cpp — the C ABI of include/rtmi.h over the gfx950 kernels: context, scene repack and
+// upload, render calls, read-backs.  There is no CPU fallback: without a HIP device every entry
+// point that needs one fails with RTMI_ERR_NO_DEVICE / RTMI_ERR_HIP.
+#include "rtmi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+static_assert(sizeof(rtmi_frame_data) == 260, "uniform block is 260 bytes");
+static_assert(sizeof(rtmi_material) == 32, "material is 32 bytes");
+static_assert(sizeof(rtmi_sphere) == 48, "sphere is 48 bytes");
+static_assert(sizeof(rtmi_mesh) == 80, "mesh is 80 bytes");
+static_assert(sizeof(rtmi_triangle) == 96, "triangle is 96 bytes");
+
+struct rtmi_ctx {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    int variant = RTMI_VARIANT_REGENERATE;
+    bool validate = false;
+    std::string err;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    float4 *own_accum = nullptr;
+    float4 *accum = nullptr;
+    uint32_t *out_rgba8 = nullptr;
+    uint32_t *hit_ids = nullptr, *chain_hash = nullptr, *rng_state = nullptr;
+    unsigned long long *counters = nullptr;
+
+    // scene
+    bool has_scene = false;
+    uint32_t n_spheres = 0, n_triangles = 0, n_meshes = 0;
+    void *scene_blob = nullptr;
+    size_t scene_blob_bytes = 0;
+    rtd::DeviceScene dscene{};
+    std::vector<rtmi_mesh> host_meshes;  // kept for range checks against frame data
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(rtmi_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP,   \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                           \
+    } while (0)
+
+size_t n_pixels(const rtmi_ctx *c) { return (size_t)c->width * c->height; }
+
+int use_device(rtmi_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RTMI_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+}  // namespace
+
+extern "C" {
+
+const char *rtmi_version(void) { return "rtmi 0.1 (gfx950, strict-fp32)"; }
+
+const char *rtmi_last_error(const rtmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out)
+{
+    if (!out) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_create: out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull)
+        return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_create: bad extent %ux%u", width, height);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, RTMI_ERR_NO_DEVICE, "rtmi_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_create: device %d out of range (0..%d)", device, count - 1);
+    rtmi_ctx *c = new (std::nothrow) rtmi_ctx();
+    if (!c) return fail(nullptr, RTMI_ERR_OUT_OF_MEMORY, "rtmi_create: host allocation failed");
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    auto bail = [&](hipError_t err, const char *what) {
+        int code = fail(nullptr, err == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP, "rtmi_create: %s: %s",
+                        what, hipGetErrorString(err));
+        rtmi_destroy(c);
+        return code;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail(e, "hipEventCreate");
+    const size_t np = n_pixels(c);
+    if ((e = hipMalloc(&c->own_accum, np * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
+    c->accum = c->own_accum;
+    if ((e = hipMalloc(&c->out_rgba8, np * 4)) != hipSuccess) return bail(e, "hipMalloc(rgba8)");
+    if ((e = hipMalloc(&c->counters, RTMI_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    // main.cpp:78-82: both images start zeroed
+    if ((e = hipMemsetAsync(c->own_accum, 0, np * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemsetAsync(c->out_rgba8, 0, np * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemsetAsync(c->counters, 0, RTMI_N_COUNTERS * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *out = c;
+    return RTMI_OK;
+}
+
+int rtmi_destroy(rtmi_ctx *c)
+{
+    if (!c) return RTMI_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    (void)hipFree(c->own_accum);
+    (void)hipFree(c->out_rgba8);
+    (void)hipFree(c->hit_ids);
+    (void)hipFree(c->chain_hash);
+    (void)hipFree(c->rng_state);
+    (void)hipFree(c->counters);
+    (void)hipFree(c->scene_blob);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RTMI_OK;
+}
+
+// Repack the reference's AoS records into the device layout of rtd::DeviceScene.  Everything
+// precomputed here (r*r, the two edges, their cross product) is ray-independent and evaluated with
+// the same single operations the shader would repeat per ray (Raytracing.comp:141, 288-290), so the
+// bits the kernels consume are the bits the shader would have produced.
+int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris, uint32_t nT,
+                      const rtmi_mesh *meshes, uint32_t nM)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if ((nS && !spheres) || (nT && !tris) || (nM && !meshes))
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_upload_scene: NULL array with non-zero count");
+    for (uint32_t m = 0; m < nM; m++) {
+        const int64_t s = meshes[m].start_triangle, n = meshes[m].num_triangles;
+        if (s < 0 || n < 0 || s + n > (int64_t)nT)
+            return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_upload_scene: mesh %u triangle range [%lld,+%lld) exceeds %u triangles",
+                        m, (long long)s, (long long)n, nT);
+    }
+    if (int rc = use_device(c)) return rc;
+
+    const size_t off_sph = 0;
+    const size_t off_tri = align_up(off_sph + (size_t)nS * 16, 256);
+    const size_t off_shd = align_up(off_tri + (size_t)nT * 64, 256);
+    const size_t off_box = align_up(off_shd + (size_t)nT * 48, 256);
+    const size_t off_mat = align_up(off_box + (size_t)nM * 32, 256);
+    const size_t total = align_up(off_mat + (size_t)(nS + nM) * 32, 256) + 256;
+    std::vector<unsigned char> blob(total, 0);
+    float *sph = reinterpret_cast<float *>(blob.data() + off_sph);
+    float *tri = reinterpret_cast<float *>(blob.data() + off_tri);
+    float *shd = reinterpret_cast<float *>(blob.data() + off_shd);
+    float *box = reinterpret_cast<float *>(blob.data() + off_box);
+    float *mat = reinterpret_cast<float *>(blob.data() + off_mat);
+
+    auto put_material = [&](uint32_t row, const rtmi_material &m) {
+        float *d = mat + 8 * (size_t)row;
+        d[0] = m.color[0]; d[1] = m.color[1]; d[2] = m.color[2]; d[3] = m.light;
+        d[4] = m.smoothness;
+    };
+    for (uint32_t i = 0; i < nS; i++) {
+        const rtmi_sphere &s = spheres[i];
+        float *d = sph + 4 * (size_t)i;
+        d[0] = s.center[0]; d[1] = s.center[1]; d[2] = s.center[2];
+        d[3] = s.radius * s.radius;
+        put_material(i, s.material);
+    }
+    for (uint32_t j = 0; j < nT; j++) {
+        const rtmi_triangle &t = tris[j];
+        float ab[3], ac[3], n[3];
+        for (int a = 0; a < 3; a++) {
+            ab[a] = t.p2[a] - t.p1[a];
+            ac[a] = t.p3[a] - t.p1[a];
+        }
+        n[0] = ab[1] * ac[2] - ac[1] * ab[2];
+        n[1] = ab[2] * ac[0] - ac[2] * ab[0];
+        n[2] = ab[0] * ac[1] - ac[0] * ab[1];
+        float *d = tri + 16 * (size_t)j;
+        for (int a = 0; a < 3; a++) {
+            d[0 + a] = t.p1[a];
+            d[4 + a] = ab[a];
+            d[8 + a] = ac[a];
+            d[12 + a] = n[a];
+        }
+        float *s = shd + 12 * (size_t)j;
+        for (int a = 0; a < 3; a++) {
+            s[0 + a] = t.n1[a];
+            s[4 + a] = t.n2[a];
+            s[8 + a] = t.n3[a];
+        }
+    }
+    for (uint32_t m = 0; m < nM; m++) {
+        const rtmi_mesh &ms = meshes[m];
+        float *d = box + 8 * (size_t)m;
+        const uint32_t start = (uint32_t)ms.start_triangle, count = (uint32_t)ms.num_triangles;
+        for (int a = 0; a < 3; a++) {
+            d[0 + a] = ms.bounding_point1[a];
+            d[4 + a] = ms.bounding_point2[a];
+        }
+        memcpy(&d[3], &start, 4);
+        memcpy(&d[7], &count, 4);
+        put_material(nS + m, ms.material);
+    }
+
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->scene_blob_bytes < total) {
+        (void)hipFree(c->scene_blob);
+        c->scene_blob = nullptr;
+        c->scene_blob_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->scene_blob, total));
+        c->scene_blob_bytes = total;
+    }
+    HIP_TRY(c, hipMemcpy(c->scene_blob, blob.data(), total, hipMemcpyHostToDevice));
+    unsigned char *base = static_cast<unsigned char *>(c->scene_blob);
+    c->dscene.sphere_geom = reinterpret_cast<const float4 *>(base + off_sph);
+    c->dscene.tri_isect = reinterpret_cast<const float4 *>(base + off_tri);
+    c->dscene.tri_shade = reinterpret_cast<const float4 *>(base + off_shd);
+    c->dscene.mesh_box = reinterpret_cast<const float4 *>(base + off_box);
+    c->dscene.materials = reinterpret_cast<const float4 *>(base + off_mat);
+    c->dscene.n_spheres = nS;
+    c->dscene.n_triangles = nT;
+    c->dscene.n_meshes = nM;
+    c->n_spheres = nS;
+    c->n_triangles = nT;
+    c->n_meshes = nM;
+    c->has_scene = true;
+    return RTMI_OK;
+}
+
+static int ensure_validation_buffers(rtmi_ctx *c)
+{
+    const size_t bytes = n_pixels(c) * sizeof(uint32_t);
+    if (!c->hit_ids) HIP_TRY(c, hipMalloc(&c->hit_ids, bytes));
+    if (!c->chain_hash) HIP_TRY(c, hipMalloc(&c->chain_hash, bytes));
+    if (!c->rng_state) HIP_TRY(c, hipMalloc(&c->rng_state, bytes));
+    return RTMI_OK;
+}
+
+int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!fd) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: frame data is NULL");
+    if (!c->has_scene) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_render: no scene uploaded");
+    if (n_frames == 0) return RTMI_OK;
+    if (fd->sphere_number > c->n_spheres || fd->mesh_number > c->n_meshes)
+        return fail(c, RTMI_ERR_SCENE_MISMATCH, "rtmi_render: frame data names %u spheres / %u meshes, scene holds %u / %u",
+                    fd->sphere_number, fd->mesh_number, c->n_spheres, c->n_meshes);
+    // The shader trusts window == image extent (no bounds check, main.cpp:376); here the image
+    // extent is fixed at creation and a mismatching window is rejected instead of read out of range.
+    if ((uint32_t)fd->window[0] != c->width || (uint32_t)fd->window[1] != c->height)
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: window %gx%g does not match context %ux%u",
+                    (double)fd->window[0], (double)fd->window[1], c->width, c->height);
+    if (int rc = use_device(c)) return rc;
+    if (c->validate)
+        if (int rc = ensure_validation_buffers(c)) return rc;
+
+    RenderParams p;
+    memset(&p, 0, sizeof p);
+    memcpy(p.inv_proj, fd->camera_inverse_projection, sizeof p.inv_proj);
+    memcpy(p.inv_view, fd->camera_inverse_view, sizeof p.inv_view);
+    memcpy(p.cam_pos, fd->camera_pos, sizeof p.cam_pos);
+    p.window_w = fd->window[0];
+    p.window_h = fd->window[1];
+    p.width = c->width;
+    p.height = c->height;
+    p.rays_per_pixel = fd->rays_per_pixel;
+    p.max_bounce = fd->max_bounce_limit;
+    memcpy(p.sky_horizon, fd->sky_color_horizon, sizeof p.sky_horizon);
+    memcpy(p.sky_zenith, fd->sky_color_zenith, sizeof p.sky_zenith);
+    memcpy(p.sun_dir, fd->sun_light_direction, sizeof p.sun_dir);
+    memcpy(p.ground, fd->ground_color, sizeof p.ground);
+    p.sun_focus = fd->sun_focus;
+    p.sun_intensity = fd->sun_intensity;
+    p.sphere_number = fd->sphere_number;
+    p.mesh_number = fd->mesh_number;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.rpp_is_pow2 = is_pow2(fd->rays_per_pixel) ? 1u : 0u;
+    p.rpp_recip = p.rpp_is_pow2 ? 1.0f / (float)fd->rays_per_pixel : 0.0f;
+    p.scene = c->dscene;
+    p.accum = c->accum;
+    p.out_rgba8 = c->out_rgba8;
+    p.hit_ids = c->hit_ids;
+    p.chain_hash = c->chain_hash;
+    p.rng_state = c->rng_state;
+    p.counters = c->counters;
+
+    int variant = c->variant;
+    if (variant == RTMI_VARIANT_WAVEFRONT)
+        return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render: the wavefront variant is not built in this version");
+    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    hipError_t e = rt_launch_render(variant, c->validate, p, c->stream);
+    if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+    return RTMI_OK;
+}
+
+int rtmi_render(rtmi_ctx *c, const rtmi_frame_data *fd)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!fd) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: frame data is NULL");
+    return rtmi_render_frames(c, fd, fd->frame_index, 1);
+}
+
+int rtmi_set_variant(rtmi_ctx *c, int variant)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE)
+        return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_variant: variant %d not available", variant);
+    c->variant = variant;
+    return RTMI_OK;
+}
+
+int rtmi_get_variant(const rtmi_ctx *c) { return c ? c->variant : RTMI_ERR_INVALID_ARGUMENT; }
+
+int rtmi_clear_accum(rtmi_ctx *c)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->accum, 0, n_pixels(c) * sizeof(float4), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->out_rgba8, 0, n_pixels(c) * 4, c->stream));
+    return RTMI_OK;
+}
+
+static int read_back(rtmi_ctx *c, void *dst, const void *src, size_t bytes, size_t need, const char *what)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!dst || bytes < need) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "%s: need a %zu-byte buffer, got %zu", what, need, bytes);
+    if (!src) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "%s: nothing to read (validation outputs not enabled?)", what);
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTMI_OK;
+}
+
+int rtmi_read_accum(rtmi_ctx *c, float *rgba, size_t bytes)
+{
+    return read_back(c, rgba, c ? c->accum : nullptr, bytes, c ? n_pixels(c) * 16 : 0, "rtmi_read_accum");
+}
+
+int rtmi_write_accum(rtmi_ctx *c, const float *rgba, size_t bytes)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    const size_t need = n_pixels(c) * 16;
+    if (!rgba || bytes < need) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_write_accum: need %zu bytes, got %zu", need, bytes);
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->accum, rgba, need, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTMI_OK;
+}
+
+int rtmi_read_output_rgba8(rtmi_ctx *c, uint8_t *rgba, size_t bytes)
+{
+    return read_back(c, rgba, c ? c->out_rgba8 : nullptr, bytes, c ? n_pixels(c) * 4 : 0, "rtmi_read_output_rgba8");
+}
+
+int rtmi_resolve_output(rtmi_ctx *c, uint32_t divisor)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (int rc = use_device(c)) return rc;
+    hipError_t e = rt_launch_resolve(c->accum, c->out_rgba8, (uint32_t)n_pixels(c), (float)divisor, c->stream);
+    if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+int rtmi_bind_accum(rtmi_ctx *c, void *device_float4)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (device_float4 && (reinterpret_cast<uintptr_t>(device_float4) & 15u))
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_bind_accum: pointer must be 16-byte aligned");
+    c->accum = device_float4 ? static_cast<float4 *>(device_float4) : c->own_accum;
+    return RTMI_OK;
+}
+
+void *rtmi_accum_device_ptr(rtmi_ctx *c) { return c ? c->accum : nullptr; }
+
+int rtmi_set_stream(rtmi_ctx *c, void *hip_stream)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->timed = false;
+    return RTMI_OK;
+}
+
+int rtmi_synchronize(rtmi_ctx *c)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTMI_OK;
+}
+
+int rtmi_last_render_ms(rtmi_ctx *c, float *ms)
+{
+    if (!c || !ms) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!c->timed) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_last_render_ms: no render call has been made");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RTMI_OK;
+}
+
+int rtmi_enable_validation(rtmi_ctx *c, int on)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    c->validate = on != 0;
+    if (c->validate) {
+        if (int rc = use_device(c)) return rc;
+        return ensure_validation_buffers(c);
+    }
+    return RTMI_OK;
+}
+
+int rtmi_read_hit_ids(rtmi_ctx *c, uint32_t *ids, size_t bytes)
+{
+    return read_back(c, ids, c ? c->hit_ids : nullptr, bytes, c ? n_pixels(c) * 4 : 0, "rtmi_read_hit_ids");
+}
+
+int rtmi_read_chain_hash(rtmi_ctx *c, uint32_t *hash, size_t bytes)
+{
+    return read_back(c, hash, c ? c->chain_hash : nullptr, bytes, c ? n_pixels(c) * 4 : 0, "rtmi_read_chain_hash");
+}
+
+int rtmi_read_rng_state(rtmi_ctx *c, uint32_t *state, size_t bytes)
+{
+    return read_back(c, state, c ? c->rng_state : nullptr, bytes, c ? n_pixels(c) * 4 : 0, "rtmi_read_rng_state");
+}
+
+int rtmi_get_counters(rtmi_ctx *c, uint64_t *counters, size_t n)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!counters || n < RTMI_N_COUNTERS) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_get_counters: need %d entries", RTMI_N_COUNTERS);
+    return read_back(c, counters, c->counters, n * 8, RTMI_N_COUNTERS * 8, "rtmi_get_counters");
+}
+
+int rtmi_reset_counters(rtmi_ctx *c)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counters, 0, RTMI_N_COUNTERS * sizeof(unsigned long long), c->stream));
+    return RTMI_OK;
+}
+
+int rtmi_selftest_math(rtmi_ctx *c, int op, const float *x, const float *y, float *out, size_t n)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!x || !out || op < 0 || op > 6 || ((op == 5 || op == 6) && !y))
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_selftest_math: bad arguments");
+    if (n == 0) return RTMI_OK;
+    if (int rc = use_device(c)) return rc;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    int rc = RTMI_OK;
+    hipError_t e = hipMalloc(&dx, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dout, n * 4);
+    if (e == hipSuccess && y) e = hipMalloc(&dy, n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && y) e = hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rt_launch_selftest(op, dx, dy, dout, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_math: %s", hipGetErrorString(e));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+"""Python host layer over the C ABI: scene building, camera/frame-data helpers and a Renderer
+object.  It mirrors what the reference's main.cpp does around the dispatch (scene literals
+main.cpp:161-185, constants main.cpp:116-153, per-frame policy main.cpp:354-363) and contains no
+rendering arithmetic of its own: every pixel comes from librtmi.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+MESH_DIR = os.path.join(os.path.dirname(abi.PKG_DIR), "assets", "meshes")
+
+# (position, yaw degrees, pitch degrees)
+DEFAULT_POSE = ((0.0, 1.0, -1.0), -90.0, 0.0)   # CameraFPS.cpp:13, CameraFPS.h:15-16; sees no geometry
+BENCH_POSE = ((0.0, 1.5, -4.5), 90.0, -15.0)    # looks at the scene from in front and above
+
+
+class RtmiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rtmi error %d: %s" % (code, message))
+        self.code = code
+
+
+def material(color, light=0.0, smoothness=0.0):
+    m = abi.Material()
+    m.color[:] = color
+    m.light = light
+    m.smoothness = smoothness
+    return m
+
+
+def sphere(center, radius, mat):
+    s = abi.Sphere()
+    s.center[:] = center
+    s.radius = radius
+    s.material = mat
+    return s
+
+
+class Scene:
+    """Sphere[] / Triangle[] / Mesh[] in the reference's AoS records."""
+
+    def __init__(self, spheres=(), triangle_capacity=1 << 16, mesh_capacity=1 << 10):
+        self.spheres = list(spheres)
+        self._tris = (abi.Triangle * triangle_capacity)()
+        self._meshes = (abi.Mesh * mesh_capacity)()
+        self._n_tris = C.c_uint32(0)
+        self._n_meshes = C.c_uint32(0)
+
+    @property
+    def n_spheres(self):
+        return len(self.spheres)
+
+    @property
+    def n_triangles(self):
+        return self._n_tris.value
+
+    @property
+    def n_meshes(self):
+        return self._n_meshes.value
+
+    @property
+    def triangles(self):
+        return self._tris
+
+    @property
+    def meshes(self):
+        return self._meshes
+
+    def sphere_array(self):
+        return (abi.Sphere * max(1, len(self.spheres)))(*self.spheres)
+
+    def load_model(self, path, mat, translate=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), quad_rule=0):
+        """LoadModel (ModelLoader.h:6-11).  Returns the number of triangles appended."""
+        rc = abi.load().rtmi_load_model(
+            os.fspath(path).encode(), self._tris, C.byref(self._n_tris), len(self._tris),
+            self._meshes, C.byref(self._n_meshes), len(self._meshes), C.byref(mat),
+            (C.c_float * 3)(*translate), (C.c_float * 3)(*scale), quad_rule)
+        if rc < 0:
+            raise RtmiError(rc, "rtmi_load_model(%s)" % path)
+        return rc
+
+
+def reference_scene(mesh_dir=MESH_DIR, quad_rule=0):
+    """main.cpp:161-185: one sphere, plane.obj scaled (2,1,2), cube.obj moved to (-1,1,0)."""
+    sc = Scene([sphere((1.0, 1.0, 0.0), 0.5, material((1.0, 1.0, 1.0), 0.0, 0.1))])
+    sc.load_model(os.path.join(mesh_dir, "plane.obj"), material((1.0, 1.0, 1.0), 0.0, 0.8),
+                  (0.0, 0.0, 0.0), (2.0, 1.0, 2.0), quad_rule)
+    sc.load_model(os.path.join(mesh_dir, "cube.obj"), material((0.9, 0.9, 0.9), 0.0, 0.1),
+                  (-1.0, 1.0, 0.0), (1.0, 1.0, 1.0), quad_rule)
+    return sc
+
+
+# Spheres-only benchmark scene: the reference's sphere, a ground sphere, and a 3x3 grid whose
+# smoothness runs 0..1, two of them emitting.  A fixed literal table, no random numbers.
+_SPHERE_SCENE_TABLE = [
+    # center,               radius,  color,              light, smoothness
+    ((1.0, 1.0, 0.0),        0.5,    (1.0, 1.0, 1.0),    0.0,   0.1),
+    ((0.0, -1000.0, 0.0),    1000.0, (0.8, 0.8, 0.8),    0.0,   0.0),
+    ((-2.4, 0.5, -1.2),      0.5,    (0.9, 0.2, 0.2),    0.0,   0.0),
+    ((-1.2, 0.5, -1.2),      0.5,    (0.2, 0.9, 0.2),    0.0,   0.125),
+    ((0.0, 0.5, -1.2),       0.5,    (1.0, 0.9, 0.7),    2.0,   0.25),
+    ((-2.4, 0.5, 0.0),       0.5,    (0.2, 0.2, 0.9),    0.0,   0.375),
+    ((-1.2, 0.5, 0.0),       0.5,    (0.9, 0.9, 0.2),    0.0,   0.5),
+    ((0.0, 0.5, 0.0),        0.5,    (0.9, 0.2, 0.9),    0.0,   0.625),
+    ((-2.4, 0.5, 1.2),       0.5,    (0.7, 0.9, 1.0),    2.0,   0.75),
+    ((-1.2, 0.5, 1.2),       0.5,    (0.2, 0.9, 0.9),    0.0,   0.875),
+    ((0.0, 0.5, 1.2),        0.5,    (0.9, 0.9, 0.9),    0.0,   1.0),
+]
+
+
+def sphere_scene():
+    return Scene([sphere(c, r, material(col, light, sm)) for c, r, col, light, sm in _SPHERE_SCENE_TABLE])
+
+
+def make_camera(width, height, pose=DEFAULT_POSE):
+    cam = abi.Camera()
+    lib = abi.load()
+    lib.rtmi_camera_init(C.byref(cam), width, height, 0.0, 0.0)
+    if pose is not None and pose != DEFAULT_POSE:
+        pos, yaw, pitch = pose
+        lib.rtmi_camera_set_pose(C.byref(cam), (C.c_float * 3)(*pos), yaw, pitch)
+        cam.moved = 0
+    return cam
+
+
+def make_frame_data(width, height, scene=None, pose=DEFAULT_POSE, rays_per_pixel=4, max_bounce=6):
+    """Frame constants of main.cpp:116-153 plus the camera block of main.cpp:355-360.
+    frame_index is left at 0 (main.cpp:120); the frame loop or render_frames supplies it."""
+    lib = abi.load()
+    fd = abi.FrameData()
+    lib.rtmi_default_frame_data(C.byref(fd))
+    cam = make_camera(width, height, pose)
+    lib.rtmi_frame_advance(C.byref(fd), C.byref(cam), 0)
+    fd.frame_index = 0
+    fd.rays_per_pixel = rays_per_pixel
+    fd.max_bounce_limit = max_bounce
+    if scene is not None:
+        fd.sphere_number = scene.n_spheres
+        fd.mesh_number = scene.n_meshes
+    return fd
+
+
+class Renderer:
+    """One context = one GPU, one image extent (rtmi_create ... rtmi_destroy)."""
+
+    def __init__(self, width, height, device=0, variant=abi.VARIANT_REGENERATE):
+        self._lib = abi.load()
+        self._ctx = C.c_void_p()
+        self.width, self.height = int(width), int(height)
+        rc = self._lib.rtmi_create(device, self.width, self.height, C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.rtmi_last_error(None)
+            self._ctx = None
+            raise RtmiError(rc, msg.decode() if msg else "rtmi_create")
+        self.set_variant(variant)
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.rtmi_last_error(self._ctx)
+            raise RtmiError(rc, msg.decode() if msg else "")
+        return rc
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.rtmi_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_variant(self, variant):
+        self._check(self._lib.rtmi_set_variant(self._ctx, variant))
+
+    def upload_scene(self, scene):
+        self._check(self._lib.rtmi_upload_scene(
+            self._ctx, scene.sphere_array(), scene.n_spheres, scene.triangles, scene.n_triangles,
+            scene.meshes, scene.n_meshes))
+
+    def render(self, fd):
+        self._check(self._lib.rtmi_render(self._ctx, C.byref(fd)))
+
+    def render_frames(self, fd, first_frame, n_frames):
+        self._check(self._lib.rtmi_render_frames(self._ctx, C.byref(fd), first_frame, n_frames))
+
+    def synchronize(self):
+        self._check(self._lib.rtmi_synchronize(self._ctx))
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.rtmi_last_render_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def clear_accum(self):
+        self._check(self._lib.rtmi_clear_accum(self._ctx))
+
+    def bind_accum(self, device_ptr):
+        self._check(self._lib.rtmi_bind_accum(self._ctx, device_ptr))
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.rtmi_set_stream(self._ctx, stream_handle))
+
+    def resolve_output(self, divisor):
+        self._check(self._lib.rtmi_resolve_output(self._ctx, divisor))
+
+    def enable_validation(self, on=True):
+        self._check(self._lib.rtmi_enable_validation(self._ctx, 1 if on else 0))
+
+    def reset_counters(self):
+        self._check(self._lib.rtmi_reset_counters(self._ctx))
+
+    def _read(self, fn, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        self._check(fn(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_accum(self):
+        return self._read(self._lib.rtmi_read_accum, np.float32, (self.height, self.width, 4))
+
+    def write_accum(self, accum):
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        self._check(self._lib.rtmi_write_accum(self._ctx, a.ctypes.data, a.nbytes))
+
+    def read_output_rgba8(self):
+        return self._read(self._lib.rtmi_read_output_rgba8, np.uint8, (self.height, self.width, 4))
+
+    def read_hit_ids(self):
+        return self._read(self._lib.rtmi_read_hit_ids, np.uint32, (self.height, self.width))
+
+    def read_chain_hash(self):
+        return self._read(self._lib.rtmi_read_chain_hash, np.uint32, (self.height, self.width))
+
+    def read_rng_state(self):
+        return self._read(self._lib.rtmi_read_rng_state, np.uint32, (self.height, self.width))
+
+    def counters(self):
+        out = np.zeros(abi.N_COUNTERS, dtype=np.uint64)
+        self._check(self._lib.rtmi_get_counters(self._ctx, out.ctypes.data, abi.N_COUNTERS))
+        return dict(zip(abi.COUNTER_NAMES, (int(v) for v in out)))
+
+    def selftest_math(self, op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32)
+            assert y.shape == x.shape
+            yp = y.ctypes.data
+        self._check(self._lib.rtmi_selftest_math(self._ctx, op, x.ctypes.data, yp, out.ctypes.data, x.size))
+        return out
+
+
+# per-event FLOP costs of the algorithm (one per add/sub/mul/min/max/div/sqrt/convert)
+FLOP_COSTS = {
+    "n_sphere_tests": 25, "n_sphere_disc_ge0": 5, "n_sphere_wins": 18, "n_box_tests": 25,
+    "n_tri_tests": 55, "n_tri_wins": 30, "n_hit_bounces": 58, "n_env_evals": 63,
+    "n_pixel_frames": 74 + 9,
+}
+
+
+def algorithmic_flops(counters):
+    return sum(cost * counters[name] for name, cost in FLOP_COSTS.items())
