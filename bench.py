@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2_spheres|c3_mesh|c4_mesh_4k]
+
+A step is one pass of the hot path over one batch: every GPU renders `--frames` frames (default
+256, 1 sample per pixel per frame, depth 8) of the workload's image in ONE kernel launch, inputs
+(scene, accumulation buffer) already resident in HBM; with N > 1 each rank owns a different
+contiguous frame range and the float4 accumulation images are summed by one RCCL all-reduce
+inside the step (weak scaling: frames per GPU fixed, total samples grow with N).
+Metric: Mpaths/s = width * height * frames * rays_per_pixel * N / seconds / 1e6 (one path = one
+Trace() call of Raytracing.comp:408-439).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the render kernel against the FP32 vector peak
+using algorithmic FLOPs from exact event counters (an instrumented launch of the same config,
+outside the timed region) and the kernel's own HIP-event time over the timed region.
+`cpu_baseline` times the CPU oracle (test infrastructure, OpenMP) on a bounded sample of the same
+workload on this machine's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (scene, width, height, max_bounce)
+    "c2_spheres": ("spheres", 1920, 1080, 8),
+    "c3_mesh": ("reference", 1920, 1080, 8),
+    "c4_mesh_4k": ("reference", 3840, 2160, 8),
+    "c1_plumbing": ("reference", 640, 360, 4),
+}
+
+
+def cpu_baseline(workload, frames_hint, budget_s):
+    """Time the oracle on a bounded sample of the workload (same image, fewer frames)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    import oracle_lib as O
+    scene_name, w, h, mb = WORKLOADS[workload]
+    case = dict(scene=scene_name, pose=cases.BENCH_POSE, size=(w, h), rpp=1, max_bounce=mb)
+    sc = cases.oracle_scene(case)
+    fd = cases.oracle_frame_data(case, sc)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    cores = max(1, min(affinity, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+    t0 = time.perf_counter()
+    O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False)
+    t1 = time.perf_counter() - t0
+    n = max(1, min(frames_hint, int(budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    O.render(fd, sc, 1, n, n_threads=cores, want_debug=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": w * h * n / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+        "sample": "%s %dx%d depth %d, frames 1..%d of the benchmark's (%.1f s of oracle time, OpenMP over rows)" % (
+            workload, w, h, mb, n, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2_spheres", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1)")
+    ap.add_argument("--variant", type=int, default=1, help="0 nested megakernel, 1 regenerating megakernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raytracer_amd as R
+    from raytracer_amd.distributed import ShardedRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                     "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene_name, width, height, max_bounce = WORKLOADS[args.workload]
+    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64}.get(args.workload, 256)
+    scene = R.sphere_scene() if scene_name == "spheres" else R.reference_scene()
+    fd = R.make_frame_data(width, height, scene, R.BENCH_POSE, rays_per_pixel=1, max_bounce=max_bounce)
+    total_frames = frames * world
+
+    renderer = R.Renderer(width, height, device=local_rank, variant=args.variant)
+    renderer.upload_scene(scene)
+    sr = ShardedRenderer(renderer, device)
+
+    def step():
+        sr.render(fd, total_frames)
+        if world > 1:
+            sr.resolve(total_frames)
+
+    # algorithmic work of this rank's launch, from exact event counters (instrumented kernel, untimed)
+    first = 1 + rank * frames
+    renderer.enable_validation(True)
+    renderer.reset_counters()
+    renderer.render_frames(fd, first, frames)
+    counters = renderer.counters()
+    renderer.enable_validation(False)
+    flops_per_launch = R.algorithmic_flops(counters)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    renderer.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    kernel_ms_total, launches = renderer.timing_read()
+    renderer.timing_reset(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths_per_step = width * height * frames * world * fd.rays_per_pixel
+    value = paths_per_step * args.steps / elapsed / 1e6
+    kernel_ms = kernel_ms_total / max(1, launches)
+    achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+    algorithmic_bytes = width * height * (16 + 4 + (0 if first == 1 else 16))   # accum write (+read) + rgba8
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+
+    result = {
+        "metric": "Mpaths/s at 1080p depth-8" if height == 1080 else "Mpaths/s",
+        "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%s: %s scene, %dx%d, %d frames x 1 spp per GPU per step, max depth %d, bench pose" % (
+                args.workload, scene_name, width, height, frames, max_bounce),
+            "variant": ["megakernel", "regenerate"][args.variant],
+            "frames_per_gpu": frames, "total_frames": total_frames,
+            "parallelism": "frame-range split x%d + RCCL all-reduce(sum) of float4 accumulation" % world if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "fp32_valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+            "kernel": ["k_megakernel", "k_regenerate"][args.variant], "kernel_ms": kernel_ms, "launches_timed": launches,
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "algorithmic_hbm_bytes_per_launch": algorithmic_bytes,
+            "hbm_gbs_algorithmic": algorithmic_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
+            "note": "strict profile: no FMA contraction, so at most half the FMA-based peak is reachable",
+        },
+        "kernel_mpaths_per_s": width * height * frames / (kernel_ms * 1e-3) / 1e6,
+        "msegments_per_s": counters["n_segments"] / (kernel_ms * 1e-3) / 1e6,
+        "counters_rank0_launch": counters,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result))
+    sr = None
+    renderer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,7 +156,8 @@ RTMI_API int rtmi_read_accum(rtmi_ctx *ctx, float *rgba, size_t bytes);
 RTMI_API int rtmi_write_accum(rtmi_ctx *ctx, const float *rgba, size_t bytes);
 /* Display image (binding 4, rgba8: sum / frame_index of the last rendered frame; RT.comp:480). */
 RTMI_API int rtmi_read_output_rgba8(rtmi_ctx *ctx, uint8_t *rgba, size_t bytes);
-/* Recompute the display image as sum / divisor (used after summing partial images of several GPUs). */
+/* Recompute the display image as sum / divisor and put the sum's alpha back to 1 (used after summing
+ * the partial images of several GPUs, whose alphas add up). */
 RTMI_API int rtmi_resolve_output(rtmi_ctx *ctx, uint32_t divisor);
 
 /* Use a caller-owned device buffer of width*height float4 as the accumulation image (for example
@@ -170,6 +171,12 @@ RTMI_API int rtmi_synchronize(rtmi_ctx *ctx);
 /* Device time of the most recent render call, from HIP events recorded around its kernels on the
  * stream they ran on; waits for them to complete. */
 RTMI_API int rtmi_last_render_ms(rtmi_ctx *ctx, float *ms);
+/* Launch timing log for measurement harnesses: after rtmi_timing_reset(ctx, 1) every render call
+ * records its own HIP event pair on its stream without synchronising; rtmi_timing_read waits for
+ * them and returns the summed device time and the number of render calls.  rtmi_timing_reset(ctx, 0)
+ * turns the log off. */
+RTMI_API int rtmi_timing_reset(rtmi_ctx *ctx, int enable);
+RTMI_API int rtmi_timing_read(rtmi_ctx *ctx, double *total_ms, uint32_t *launches);
 
 /* Validation outputs (the shader exports none; ids are defined as: sphere i -> i, triangle j ->
  * sphere_number + j, miss -> RTMI_MISS_ID).  Enabling them selects instrumented kernels that also

@@ -444,10 +444,24 @@ int orc_render(const orc_frame_data *fd_in,
                float *accum, uint8_t *out_rgba8, uint32_t *prim_id, uint32_t *chain_hash,
                uint32_t *rng_state, uint64_t *counters, int n_threads)
 {
+    if (!fd_in) return -1;
+    return orc_render_rows(fd_in, spheres, tris, n_tris, meshes, first_frame, n_frames, accum, out_rgba8,
+                           prim_id, chain_hash, rng_state, counters, n_threads, 0, (uint32_t)fd_in->window[1]);
+}
+
+/* Same, restricted to image rows y0 <= y < y1 (full-size buffers; other rows are left untouched).
+ * A pixel's result does not depend on any other pixel, so this equals the same rows of a full render. */
+int orc_render_rows(const orc_frame_data *fd_in,
+                    const orc_sphere *spheres, const orc_triangle *tris, uint32_t n_tris,
+                    const orc_mesh *meshes,
+                    uint32_t first_frame, uint32_t n_frames,
+                    float *accum, uint8_t *out_rgba8, uint32_t *prim_id, uint32_t *chain_hash,
+                    uint32_t *rng_state, uint64_t *counters, int n_threads, uint32_t y0, uint32_t y1)
+{
     (void)n_tris;
     if (!fd_in || !accum) return -1;
     const uint32_t W = (uint32_t)fd_in->window[0], H = (uint32_t)fd_in->window[1];
-    if (W == 0 || H == 0) return -1;
+    if (W == 0 || H == 0 || y0 > y1 || y1 > H) return -1;
     counters_t total;
     memset(&total, 0, sizeof total);
 #ifdef _OPENMP
@@ -462,7 +476,7 @@ int orc_render(const orc_frame_data *fd_in,
         memset(&cn, 0, sizeof cn);
         orc_frame_data fd = *fd_in;
 #pragma omp for schedule(dynamic, 4)
-        for (uint32_t y = 0; y < H; y++) {
+        for (uint32_t y = y0; y < y1; y++) {
             for (uint32_t x = 0; x < W; x++) {
                 size_t px = (size_t)y * W + x;
                 float of[3], df[3];

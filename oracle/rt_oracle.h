@@ -138,6 +138,14 @@ int orc_render(const orc_frame_data *fd,
                float *accum, uint8_t *out_rgba8, uint32_t *prim_id, uint32_t *chain_hash,
                uint32_t *rng_state, uint64_t *counters, int n_threads);
 
+/* Same for image rows y0 <= y < y1 only (buffers are full size; other rows are left untouched). */
+int orc_render_rows(const orc_frame_data *fd,
+                    const orc_sphere *spheres, const orc_triangle *tris, uint32_t n_tris,
+                    const orc_mesh *meshes,
+                    uint32_t first_frame, uint32_t n_frames,
+                    float *accum, uint8_t *out_rgba8, uint32_t *prim_id, uint32_t *chain_hash,
+                    uint32_t *rng_state, uint64_t *counters, int n_threads, uint32_t y0, uint32_t y1);
+
 #ifdef __cplusplus
 }
 #endif

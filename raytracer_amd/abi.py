@@ -108,6 +108,8 @@ PROTOTYPES = {
     "rtmi_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "rtmi_synchronize": (C.c_int, [_ctx]),
     "rtmi_last_render_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    "rtmi_timing_reset": (C.c_int, [_ctx, C.c_int]),
+    "rtmi_timing_read": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "rtmi_enable_validation": (C.c_int, [_ctx, C.c_int]),
     "rtmi_read_hit_ids": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "rtmi_read_chain_hash": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),

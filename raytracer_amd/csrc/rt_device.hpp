@@ -250,7 +250,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
                         if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
                             best.t = t;
                             best.prim = n_spheres + j;
-                            best.mat = n_spheres + m;
+                            best.mat = sc.n_spheres + m;  // material rows follow the uploaded sphere count
                             best.u = u;
                             best.v = v;
                         }

@@ -255,13 +255,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
     finish_pixel<VALIDATE>(p, s, sum, p.first_frame + p.n_frames - 1u, first_prim, hash, rng, cn);
 }
 
-// display image from an already summed accumulation image: rgba8 = unorm8(sum / divisor)
-__global__ __launch_bounds__(kBlockThreads) void k_resolve(const float4 *__restrict__ accum, uint32_t *__restrict__ out,
+// display image from an already summed accumulation image: rgba8 = unorm8(sum / divisor).  Also puts
+// the alpha of the sum back to 1 (a sum of k partial images carries alpha k).
+__global__ __launch_bounds__(kBlockThreads) void k_resolve(float4 *__restrict__ accum, uint32_t *__restrict__ out,
                                                            uint32_t n_pixels, float divisor)
 {
     const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
     if (i >= n_pixels) return;
-    const float4 a = accum[i];
+    float4 a = accum[i];
+    if (a.w != 1.0f) {
+        a.w = 1.0f;
+        accum[i] = a;
+    }
     const uint32_t r = unorm8(a.x / divisor), g = unorm8(a.y / divisor), b = unorm8(a.z / divisor);
     out[i] = r | (g << 8) | (b << 16) | 0xFF000000u;
 }
@@ -316,7 +321,7 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     return hipGetLastError();
 }
 
-hipError_t rt_launch_resolve(const float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream)
+hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream)
 {
     const dim3 grid((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1);
     hipLaunchKernelGGL(k_resolve, grid, dim3(kBlockThreads, 1, 1), 0, stream, accum, out, n_pixels, divisor);

@@ -34,5 +34,5 @@ struct RenderParams {
 
 const char *rt_kernel_name(int variant);
 hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream);
-hipError_t rt_launch_resolve(const float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
+hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
 hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);

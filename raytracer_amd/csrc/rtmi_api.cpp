@@ -33,6 +33,10 @@ struct rtmi_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // launch timing log: one event pair per render call since the last rtmi_timing_reset
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    bool ev_logging = false;
 
     float4 *own_accum = nullptr;
     float4 *accum = nullptr;
@@ -149,6 +153,10 @@ int rtmi_destroy(rtmi_ctx *c)
     (void)hipFree(c->scene_blob);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (auto &pr : c->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTMI_OK;
@@ -320,11 +328,23 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     int variant = c->variant;
     if (variant == RTMI_VARIANT_WAVEFRONT)
         return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render: the wavefront variant is not built in this version");
-    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;
+    if (c->ev_logging) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(c, hipEventCreate(&a));
+            HIP_TRY(c, hipEventCreate(&b));
+            c->ev_pool.emplace_back(a, b);
+        }
+        ev0 = c->ev_pool[c->ev_used].first;
+        ev1 = c->ev_pool[c->ev_used].second;
+        c->ev_used++;
+    }
+    HIP_TRY(c, hipEventRecord(ev0, c->stream));
     hipError_t e = rt_launch_render(variant, c->validate, p, c->stream);
     if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
-    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-    c->timed = true;
+    HIP_TRY(c, hipEventRecord(ev1, c->stream));
+    c->timed = !c->ev_logging;
     return RTMI_OK;
 }
 
@@ -391,6 +411,7 @@ int rtmi_resolve_output(rtmi_ctx *c, uint32_t divisor)
 {
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     if (int rc = use_device(c)) return rc;
+    if (divisor == 0) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_resolve_output: divisor is 0");
     hipError_t e = rt_launch_resolve(c->accum, c->out_rgba8, (uint32_t)n_pixels(c), (float)divisor, c->stream);
     if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
     return RTMI_OK;
@@ -430,6 +451,31 @@ int rtmi_last_render_ms(rtmi_ctx *c, float *ms)
     if (int rc = use_device(c)) return rc;
     HIP_TRY(c, hipEventSynchronize(c->ev_stop));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RTMI_OK;
+}
+
+int rtmi_timing_reset(rtmi_ctx *c, int enable)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    c->ev_used = 0;
+    c->ev_logging = enable != 0;
+    c->timed = false;
+    return RTMI_OK;
+}
+
+int rtmi_timing_read(rtmi_ctx *c, double *total_ms, uint32_t *launches)
+{
+    if (!c || !total_ms || !launches) return RTMI_ERR_INVALID_ARGUMENT;
+    if (int rc = use_device(c)) return rc;
+    double sum = 0.0;
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (uint32_t)c->ev_used;
     return RTMI_OK;
 }
 

@@ -1,0 +1,69 @@
+"""Multi-GPU rendering: one process per GPU, frames split by contiguous range, one sum-reduce of the
+float4 accumulation images at the end.
+
+A frame's contribution to a pixel depends only on (x, y, frame_index, scene, camera): the seed is a
+pure function of them (Raytracing.comp:462) and nothing is read back from earlier frames except the
+running sum (Raytracing.comp:471-472).  The samples inside one frame share an RNG stream
+(Raytracing.comp:464-468), so the smallest unit that can move to another GPU is a whole frame.
+Every rank therefore renders its own frame range into a zeroed local image (adding into zero equals
+the shader's frame_index == 1 overwrite) and the images are summed with one collective
+(torch.distributed: RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def split_frames(total_frames, world_size, rank, first_frame=1):
+    """Contiguous, balanced frame ranges: returns (first_frame_of_rank, n_frames_of_rank)."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("bad rank %d / world size %d" % (rank, world_size))
+    q, rem = divmod(int(total_frames), world_size)
+    n = q + (1 if rank < rem else 0)
+    start = first_frame + rank * q + min(rank, rem)
+    return start, n
+
+
+def render_sharded(render_range, accum, total_frames, first_frame=1, group=None, dst=None):
+    """Render this rank's share of frames first_frame .. first_frame+total_frames-1 into `accum`
+    (a [H, W, 4] float32 tensor the renderer is bound to) and sum the images over all ranks.
+
+    render_range(first, n) must add frames first .. first+n-1 into `accum`, overwriting instead when
+    first == 1, exactly as rtmi_render_frames does.  With dst=None every rank ends up with the sum
+    (all-reduce); otherwise only rank dst does (reduce).  Returns (first, n) of this rank.  The
+    alpha channel of the sum equals the number of ranks that rendered something; the caller puts
+    it back to 1 (rtmi_resolve_output does)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, n = split_frames(total_frames, world, rank, first_frame)
+    if world > 1 or first != 1 or n == 0:
+        # ranks other than the owner of frame 1 add into their buffer, so it has to start at zero;
+        # the owner of frame 1 overwrites, but is zeroed too so every rank runs the same sequence
+        accum.zero_()
+    if n > 0:
+        render_range(first, n)
+    if world > 1:
+        if dst is None:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return first, n
+
+
+class ShardedRenderer:
+    """A Renderer bound to a torch tensor so that torch.distributed can reduce the accumulation
+    image in place; kernels are launched on torch's current stream so the collective is ordered
+    after them without a host synchronisation."""
+
+    def __init__(self, renderer, device):
+        self.renderer = renderer
+        self.device = torch.device(device)
+        self.accum = torch.zeros((renderer.height, renderer.width, 4), dtype=torch.float32, device=self.device)
+        renderer.bind_accum(self.accum.data_ptr())
+        renderer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def render(self, fd, total_frames, first_frame=1, group=None, dst=None):
+        rng = render_sharded(lambda first, n: self.renderer.render_frames(fd, first, n), self.accum,
+                             total_frames, first_frame, group, dst)
+        return rng
+
+    def resolve(self, total_frames):
+        self.renderer.resolve_output(total_frames)

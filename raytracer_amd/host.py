@@ -201,6 +201,15 @@ class Renderer:
         self._check(self._lib.rtmi_last_render_ms(self._ctx, C.byref(ms)))
         return ms.value
 
+    def timing_reset(self, enable=True):
+        self._check(self._lib.rtmi_timing_reset(self._ctx, 1 if enable else 0))
+
+    def timing_read(self):
+        """(summed device milliseconds, number of render calls) since timing_reset."""
+        total, n = C.c_double(), C.c_uint32()
+        self._check(self._lib.rtmi_timing_read(self._ctx, C.byref(total), C.byref(n)))
+        return total.value, n.value
+
     def clear_accum(self):
         self._check(self._lib.rtmi_clear_accum(self._ctx))
 

@@ -112,6 +112,8 @@ def lib():
                              C.POINTER(Mesh), C.c_uint32, C.c_uint32,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int]
+    L.orc_render_rows.restype = C.c_int
+    L.orc_render_rows.argtypes = L.orc_render.argtypes + [C.c_uint32, C.c_uint32]
     _lib = L
     return L
 
@@ -184,9 +186,11 @@ def frame_data(width, height, pos=(0.0, 1.0, -1.0), yaw=-90.0, pitch=0.0, rpp=4,
     return fd
 
 
-def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug=True):
-    """Returns dict(accum, rgba8, prim_id, chain_hash, rng_state, counters)."""
+def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug=True, rows=None):
+    """Returns dict(accum, rgba8, prim_id, chain_hash, rng_state, counters).  rows=(y0, y1) renders
+    only those image rows (the arrays stay full size)."""
     W, H = int(fd.window[0]), int(fd.window[1])
+    y0, y1 = rows if rows is not None else (0, H)
     if accum is None:
         accum = np.zeros((H, W, 4), dtype=np.float32)
     else:
@@ -196,13 +200,13 @@ def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug
     chain = np.zeros((H, W), dtype=np.uint32)
     rng = np.zeros((H, W), dtype=np.uint32)
     counters = np.zeros(N_COUNTERS, dtype=np.uint64)
-    rc = lib().orc_render(C.byref(fd), scene.spheres, scene.tris, scene.n_tris.value, scene.meshes,
-                          first_frame, n_frames,
-                          accum.ctypes.data, rgba8.ctypes.data,
-                          prim.ctypes.data if want_debug else None,
-                          chain.ctypes.data if want_debug else None,
-                          rng.ctypes.data if want_debug else None,
-                          counters.ctypes.data, n_threads)
+    rc = lib().orc_render_rows(C.byref(fd), scene.spheres, scene.tris, scene.n_tris.value, scene.meshes,
+                               first_frame, n_frames,
+                               accum.ctypes.data, rgba8.ctypes.data,
+                               prim.ctypes.data if want_debug else None,
+                               chain.ctypes.data if want_debug else None,
+                               rng.ctypes.data if want_debug else None,
+                               counters.ctypes.data, n_threads, y0, y1)
     if rc != 0:
         raise RuntimeError("orc_render failed: %d" % rc)
     return dict(accum=accum, rgba8=rgba8, prim_id=prim, chain_hash=chain, rng_state=rng,

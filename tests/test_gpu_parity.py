@@ -1,0 +1,323 @@
+"""GPU parity tests (run on an MI355X with `-m gpu`).  Everything goes through the C ABI
+(include/rtmi.h via ctypes).  The bar is bit-exactness against the CPU oracle for every output:
+accumulation image (float32 bit patterns), display image, primitive ids, per-pixel id-chain
+hash, RNG state and event counters."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, 1]
+
+
+def gpu_render(rtmi, case, variant, validate=True, per_frame=False):
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        r.enable_validation(validate)
+        if case.get("seed_accum"):
+            r.write_accum(cases.seed_accum(case))
+        if per_frame:
+            for f in range(case["first"], case["first"] + case["n"]):
+                fd.frame_index = f
+                r.render(fd)
+        else:
+            r.render_frames(fd, case["first"], case["n"])
+        out = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8())
+        if validate:
+            out.update(prim_id=r.read_hit_ids(), chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state(),
+                       counters=r.counters())
+    return out
+
+
+def assert_same(got, want, keys=("rgba8", "prim_id", "chain_hash", "rng_state")):
+    # booleans are computed first so a failure prints a short message, not the arrays
+    same = cases.bits_equal(got["accum"], want["accum"])
+    assert same, "accumulation image differs: %d pixels, max abs %g" % (
+        int((got["accum"] != want["accum"]).any(axis=-1).sum()), float(np.nanmax(np.abs(got["accum"] - want["accum"]))))
+    for k in keys:
+        if k in got:
+            same = np.array_equal(got[k], want[k])
+            assert same, "%s differs in %d pixels" % (k, int((got[k] != want[k]).sum()))
+    if "counters" in got:
+        same = got["counters"] == want["counters"]
+        assert same, "counters differ: %r vs %r" % (got["counters"], want["counters"])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_golden_and_oracle(rtmi, oracle, name, variant):
+    case = cases.CASES[name]
+    got = gpu_render(rtmi, case, variant)
+    assert_same(got, cases.load_golden(name))
+    assert_same(got, cases.run_oracle(case))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_host_sides_agree(rtmi, oracle, variant):
+    """The product's scene/camera bytes equal the oracle's, so both render the same inputs."""
+    for case in cases.CASES.values():
+        sc, osc = cases.product_scene(case), cases.oracle_scene(case)
+        assert bytes(cases.product_frame_data(case, sc)) == bytes(cases.oracle_frame_data(case, osc))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_frame_loop_equals_batched_launch(rtmi, variant):
+    """rtmi_render called once per frame (the reference's loop) == one rtmi_render_frames launch."""
+    for name in ("c3_mesh_bench_pose", "reference_defaults_rpp4_continue"):
+        case = cases.CASES[name]
+        a = gpu_render(rtmi, case, variant, per_frame=True)
+        b = gpu_render(rtmi, case, variant, per_frame=False)
+        assert cases.bits_equal(a["accum"], b["accum"]) and np.array_equal(a["rgba8"], b["rgba8"])
+        assert np.array_equal(a["rng_state"], b["rng_state"]) and np.array_equal(a["prim_id"], b["prim_id"])
+        assert_same(b, cases.load_golden(name), keys=("rgba8", "prim_id", "rng_state"))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_uninstrumented_kernels_give_the_same_image(rtmi, variant):
+    for name in ("c2_spheres_bench_pose", "ragged_size_rpp3"):
+        got = gpu_render(rtmi, cases.CASES[name], variant, validate=False)
+        want = cases.load_golden(name)
+        assert cases.bits_equal(got["accum"], want["accum"]) and np.array_equal(got["rgba8"], want["rgba8"])
+
+
+def test_reset_and_accumulate_semantics(rtmi):
+    case = cases.CASES["c3_mesh_bench_pose"]
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    with rtmi.Renderer(w, h) as r:
+        r.upload_scene(sc)
+        r.write_accum(np.full((h, w, 4), 55.0, dtype=np.float32))
+        r.render_frames(fd, 1, 3)                 # frame_index 1 overwrites the junk
+        a = r.read_accum()
+        r.render_frames(fd, 4, 5)                 # later frames add
+        b = r.read_accum()
+        r.render_frames(fd, 1, 8)                 # "camera moved": starts over
+        c = r.read_accum()
+        r.clear_accum()
+        assert not r.read_accum().any() and not r.read_output_rgba8().any()
+    want = cases.load_golden("c3_mesh_bench_pose")
+    assert cases.bits_equal(b, want["accum"]) and cases.bits_equal(c, want["accum"])
+    assert not cases.bits_equal(a, b) and (a[..., 3] == 1.0).all()
+
+
+def test_display_image_is_sum_over_frame_index(rtmi):
+    case = cases.CASES["c2_spheres_bench_pose"]
+    got = gpu_render(rtmi, case, 1, validate=False)
+    mean = got["accum"][..., :3] / np.float32(case["first"] + case["n"] - 1)
+    want = np.rint(np.clip(mean, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(got["rgba8"][..., :3], want) and (got["rgba8"][..., 3] == 255).all()
+
+
+def test_resolve_output(rtmi):
+    case = cases.CASES["c3_mesh_bench_pose"]
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    with rtmi.Renderer(w, h) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 8)
+        acc = r.read_accum()
+        acc[..., 3] = 2.0                          # as if two partial images had been summed
+        r.write_accum(acc * np.float32(2.0))
+        r.resolve_output(16)
+        out, fixed = r.read_output_rgba8(), r.read_accum()
+    assert np.array_equal(out, cases.load_golden("c3_mesh_bench_pose")["rgba8"])
+    assert (fixed[..., 3] == 1.0).all() and np.array_equal(fixed[..., :3], acc[..., :3] * np.float32(2.0))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_edge_shapes_and_empty_scenes(rtmi, oracle, variant):
+    base = cases.CASES["c3_mesh_bench_pose"]
+    for size in ((1, 1), (17, 9), (16, 16), (15, 33)):
+        case = dict(base, size=size, n=2)
+        assert_same(gpu_render(rtmi, case, variant), cases.run_oracle(case))
+    # no spheres and no meshes in the frame data: every path is a sky path
+    case = dict(base, size=(24, 12), n=2)
+    sc, osc = cases.product_scene(case), cases.oracle_scene(case)
+    fd, ofd = cases.product_frame_data(case, sc), cases.oracle_frame_data(case, osc)
+    for ns, nm in ((0, 0), (1, 0), (0, 2), (0, 1)):
+        fd.sphere_number, fd.mesh_number = ns, nm
+        ofd.sphere_count, ofd.mesh_count = ns, nm
+        with rtmi.Renderer(24, 12, variant=variant) as r:
+            r.upload_scene(sc)
+            r.enable_validation(True)
+            r.render_frames(fd, 1, 2)
+            got = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                       chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state(), counters=r.counters())
+        assert_same(got, oracle.render(ofd, osc, 1, 2))
+    # an uploaded scene with no primitives at all
+    empty = rtmi.Scene()
+    fd.sphere_number = fd.mesh_number = 0
+    ofd.sphere_count = ofd.mesh_count = 0
+    with rtmi.Renderer(24, 12, variant=variant) as r:
+        r.upload_scene(empty)
+        r.render_frames(fd, 1, 2)
+        assert cases.bits_equal(r.read_accum(), oracle.render(ofd, osc, 1, 2)["accum"])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_zero_bounces_and_many_samples(rtmi, oracle, variant):
+    base = cases.CASES["c3_mesh_bench_pose"]
+    for mb, rpp in ((0, 1), (1, 1), (2, 7), (16, 2)):
+        case = dict(base, size=(40, 24), max_bounce=mb, rpp=rpp, n=2)
+        assert_same(gpu_render(rtmi, case, variant), cases.run_oracle(case))
+
+
+def test_large_frame_indices(rtmi, oracle):
+    # frame indices as config C4 uses them (last eighth of 4096 frames), seed arithmetic wraps in uint32
+    case = dict(cases.CASES["c3_mesh_bench_pose"], size=(48, 27), first=3585, n=3)
+    assert_same(gpu_render(rtmi, case, 1), cases.run_oracle(case))
+
+
+def test_error_paths(rtmi):
+    a = rtmi.abi
+    case = cases.CASES["c3_mesh_bench_pose"]
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    with rtmi.Renderer(w, h) as r:
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.render_frames(fd, 1, 1)
+        assert e.value.code == a.ERR_NO_SCENE
+        r.upload_scene(sc)
+        fd.sphere_number = 5
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.render_frames(fd, 1, 1)
+        assert e.value.code == a.ERR_SCENE_MISMATCH
+        fd.sphere_number = 1
+        fd.window[0] = w + 1
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.render_frames(fd, 1, 1)
+        assert e.value.code == a.ERR_INVALID_ARGUMENT
+        fd.window[0] = w
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.set_variant(7)
+        assert e.value.code == a.ERR_UNSUPPORTED
+        small = np.zeros(4, dtype=np.float32)
+        assert a.load().rtmi_read_accum(r._ctx, small.ctypes.data, small.nbytes) == a.ERR_INVALID_ARGUMENT
+        with pytest.raises(rtmi.RtmiError):
+            r.read_hit_ids()                      # validation outputs were never enabled
+        bad = rtmi.Scene()
+        bad._meshes[0].start_triangle, bad._meshes[0].num_triangles = 0, 3
+        bad._n_meshes.value = 1
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.upload_scene(bad)                   # mesh names triangles that do not exist
+        assert e.value.code == a.ERR_INVALID_ARGUMENT
+        r.render_frames(fd, 1, 1)                 # the context is still usable
+        r.synchronize()
+    ctx = C.c_void_p()
+    assert a.load().rtmi_create(99, 8, 8, C.byref(ctx)) == a.ERR_INVALID_ARGUMENT
+
+
+def test_device_arithmetic_contract(rtmi, oracle):
+    """The primitives the contract relies on: IEEE divide / sqrt / reciprocal, exact uint->float
+    scaling, and the polynomial log2 / exp2 / pow, against numpy and the oracle bit for bit."""
+    rs = np.random.RandomState(99)
+    bits = rs.randint(0, 2**32, size=1 << 18, dtype=np.uint64).astype(np.uint32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 1e-39, 1.17549435e-38, 3.4028235e38,
+                        0.5, 2.0, 3.0, 1e-6, 0.0001, 1.0000001, 0.99999994], dtype=np.float32)
+    x = np.concatenate([bits.view(np.float32), special, rs.uniform(-4, 4, 4096).astype(np.float32)])
+    y = np.concatenate([np.roll(bits, 7).view(np.float32), special[::-1], rs.uniform(-4, 4, 4096).astype(np.float32)])
+    L = oracle.lib()
+    with rtmi.Renderer(8, 8) as r, np.errstate(all="ignore"):
+        assert cases.bits_equal(r.selftest_math(0, x), np.float32(1.0) / x)
+        assert cases.bits_equal(r.selftest_math(1, x), np.sqrt(x))
+        assert cases.bits_equal(r.selftest_math(6, x, y), x / y)
+        u = x.view(np.uint32)
+        assert cases.bits_equal(r.selftest_math(4, x), u.astype(np.float32) * np.float32(2.0 ** -32))
+        n = 6000
+        xs = np.concatenate([x[:n], special, rs.uniform(0, 1, n).astype(np.float32), rs.uniform(-160, 140, n).astype(np.float32)])
+        ys = np.concatenate([y[:n], special[::-1], np.full(n, 0.35, dtype=np.float32), rs.uniform(0, 8, n).astype(np.float32)])
+        want_log = np.array([L.orc_log2(float(v)) for v in xs], dtype=np.float32)
+        want_exp = np.array([L.orc_exp2(float(v)) for v in xs], dtype=np.float32)
+        want_pow = np.array([L.orc_pow(float(a), float(b)) for a, b in zip(xs, ys)], dtype=np.float32)
+        assert cases.bits_equal(r.selftest_math(2, xs), want_log)
+        assert cases.bits_equal(r.selftest_math(3, xs), want_exp)
+        assert cases.bits_equal(r.selftest_math(5, xs, ys), want_pow)
+
+
+def test_external_buffer_and_stream(rtmi):
+    """Accumulate into a torch tensor on torch's stream (the multi-GPU path's plumbing)."""
+    import torch
+    case = cases.CASES["c3_mesh_bench_pose"]
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    dev = torch.device("cuda:0")
+    from raytracer_amd.distributed import ShardedRenderer
+    with rtmi.Renderer(w, h) as r:
+        r.upload_scene(sc)
+        sr = ShardedRenderer(r, dev)
+        first, n = sr.render(fd, 8)
+        assert (first, n) == (1, 8)
+        sr.resolve(8)
+        torch.cuda.synchronize(dev)
+        got = sr.accum.cpu().numpy()
+        out = r.read_output_rgba8()
+        r.bind_accum(None)
+        r.set_stream(None)
+    want = cases.load_golden("c3_mesh_bench_pose")
+    assert cases.bits_equal(got, want["accum"]) and np.array_equal(out, want["rgba8"])
+
+
+# ---- BASELINE sizes: 1920x1080, depth 8 -----------------------------------------------------------
+
+FULL = dict(size=(1920, 1080), rpp=1, max_bounce=8, first=1)
+
+
+@pytest.mark.parametrize("scene", ["spheres", "reference"])
+def test_full_size_rows_against_oracle(rtmi, oracle, scene):
+    """At the benchmark resolution the oracle checks whole rows (a pixel depends on no other pixel,
+    so rows of a full render can be checked on their own): bottom, horizon, middle and top rows."""
+    case = dict(FULL, scene=scene, pose=cases.BENCH_POSE, n=6)
+    got = gpu_render(rtmi, case, 1)
+    again = gpu_render(rtmi, case, 0)
+    assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
+    assert np.array_equal(got["chain_hash"], again["chain_hash"])
+    osc = cases.oracle_scene(case)
+    ofd = cases.oracle_frame_data(case, osc)
+    for y0 in (0, 300, 539, 1079):
+        want = oracle.render(ofd, osc, 1, 6, rows=(y0, y0 + 1))
+        for k in ("accum", "rgba8", "prim_id", "chain_hash", "rng_state"):
+            assert np.array_equal(got[k][y0].view(np.uint32) if k == "accum" else got[k][y0],
+                                  want[k][y0].view(np.uint32) if k == "accum" else want[k][y0]), (k, y0)
+    c = got["counters"]
+    npx = 1920 * 1080
+    assert c["n_pixel_frames"] == npx * 6 and c["n_paths"] == npx * 6
+    assert c["n_segments"] == c["n_hit_bounces"] + c["n_env_evals"]
+    assert c["n_hit_bounces"] == c["n_sphere_wins"] + c["n_tri_wins"]
+    assert c["n_sphere_tests"] == c["n_segments"] * len(cases.sphere_table() if scene == "spheres" else [0])
+    assert c["n_env_evals"] <= c["n_paths"]
+
+
+def test_full_size_split_invariance_256_frames(rtmi):
+    """BASELINE config (1080p, 256 frames, depth 8): one launch == four launches of 64 frames ==
+    the other variant, bit for bit; a second run reproduces the first."""
+    case = dict(FULL, scene="spheres", pose=cases.BENCH_POSE)
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    with rtmi.Renderer(1920, 1080, variant=1) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 256)
+        one = r.read_accum()
+        out_one = r.read_output_rgba8()
+        for k in range(4):
+            r.render_frames(fd, 1 + 64 * k, 64)
+        four = r.read_accum()
+        out_four = r.read_output_rgba8()
+        r.set_variant(0)
+        r.render_frames(fd, 1, 256)
+        nested = r.read_accum()
+    assert np.array_equal(one.view(np.uint32), four.view(np.uint32)) and np.array_equal(out_one, out_four)
+    assert np.array_equal(one.view(np.uint32), nested.view(np.uint32))
+    assert np.isfinite(one).all() and (one[..., 3] == 1.0).all()
+    mean = one[..., :3] / 256.0
+    assert 0.2 < mean.mean() < 2.0

@@ -1,0 +1,180 @@
+"""Host side kept from the reference, exercised through the C ABI on the CPU: LoadModel, camera,
+frame policy, image writers.  The oracle's independent C restatement is the comparison."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+
+def test_reference_scene_matches_oracle(rtmi, oracle):
+    for rule in (0, 1):
+        a = rtmi.reference_scene(quad_rule=rule)
+        b = oracle.reference_scene(quad_rule=rule)
+        assert (a.n_spheres, a.n_triangles, a.n_meshes) == (1, 14, 2)
+        assert bytes(a.triangles)[:96 * 14] == bytes(b.tris)[:96 * 14]
+        assert bytes(a.meshes)[:80 * 2] == bytes(b.meshes)[:80 * 2]
+        assert bytes(a.sphere_array())[:48] == bytes(b.spheres)[:48]
+
+
+def test_load_model_missing_file_appends_nothing(rtmi):
+    sc = rtmi.Scene()
+    with pytest.raises(rtmi.RtmiError) as e:
+        sc.load_model("/nonexistent/none.obj", rtmi.material((1, 1, 1)))
+    assert e.value.code == rtmi.abi.ERR_IO
+    assert sc.n_triangles == 0 and sc.n_meshes == 0
+
+
+def test_load_model_formats(rtmi, tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("# comment\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nvn 0 0 1\n"
+                 "f 1 2 3\n"            # plain indices, no normals
+                 "f 1/1 2/1 3/1\n"      # v/vt
+                 "f 1//1 2//1 3//1\n"   # v//vn
+                 "f -5//-1 -4//-1 -3//-1\n"  # negative (relative) indices
+                 "f 1 2 3 4 5\n")       # pentagon -> fan of 3
+    sc = rtmi.Scene()
+    n = sc.load_model(p, rtmi.material((1, 1, 1)), translate=(10, 0, 0), scale=(2, 3, 4))
+    assert n == 7 and sc.n_meshes == 1
+    t = sc.triangles
+    assert list(t[0].p2)[:3] == [12.0, 0.0, 0.0] and list(t[0].n1)[:3] == [0.0, 0.0, 0.0]
+    assert list(t[2].n1)[:3] == [0.0, 0.0, 1.0]
+    assert bytes(t[3])[:96] == bytes(t[2])[:96]
+    assert list(t[6].p3)[:3] == [11.0, 6.0, 0.0]
+    m = sc.meshes[0]
+    assert list(m.bounding_point1)[:3] == [10.0, 0.0, 0.0] and list(m.bounding_point2)[:3] == [12.0, 6.0, 0.0]
+    # an empty file still appends a mesh record with the seed box, as the reference does
+    e = tmp_path / "e.obj"
+    e.write_text("# nothing\n")
+    assert sc.load_model(e, rtmi.material((1, 1, 1))) == 0
+    m = sc.meshes[1]
+    assert (m.start_triangle, m.num_triangles) == (7, 0)
+    assert list(m.bounding_point1)[:3] == [1024.0] * 3 and list(m.bounding_point2)[:3] == [-1024.0] * 3
+
+
+def test_load_model_capacity(rtmi):
+    sc = rtmi.Scene(triangle_capacity=5)
+    with pytest.raises(rtmi.RtmiError) as e:
+        sc.load_model(os.path.join(rtmi.host.MESH_DIR, "cube.obj"), rtmi.material((1, 1, 1)))
+    assert e.value.code == rtmi.abi.ERR_OUT_OF_MEMORY and sc.n_triangles == 0
+
+
+@pytest.mark.parametrize("pose", [cases.DEFAULT_POSE, cases.BENCH_POSE, ((3.0, 2.0, 1.0), 37.5, 20.0)])
+def test_frame_data_matches_oracle(rtmi, oracle, pose):
+    sc = rtmi.reference_scene()
+    osc = oracle.reference_scene()
+    for w, h in ((1280, 720), (1920, 1080), (37, 19)):
+        fd = rtmi.make_frame_data(w, h, sc, pose, 4, 6)
+        ofd = oracle.frame_data(w, h, *pose, rpp=4, max_bounce=6, scene=osc)
+        assert bytes(fd) == bytes(ofd)
+
+
+def test_default_frame_constants(rtmi):
+    fd = rtmi.abi.FrameData()
+    rtmi.abi.load().rtmi_default_frame_data(C.byref(fd))
+    assert (fd.rays_per_pixel, fd.max_bounce_limit, fd.frame_index) == (4, 6, 0)
+    assert np.allclose(fd.sun_light_direction[:], [-0.4, -0.4, -0.4, 0.0])
+    assert np.allclose(fd.sky_color_horizon[:], [0.7, 0.3, 0.1, 0.0])
+    assert np.allclose(fd.sky_color_zenith[:], [0.2, 0.56, 0.95, 0.0])
+    assert np.allclose(fd.ground_color[:], [0.9, 0.9, 0.9, 0.0])
+    assert fd.sun_focus == 1.0 and fd.sun_intensity == 1.0
+
+
+def _update(rtmi, cam, dt=0.5, **keys):
+    inp = rtmi.abi.CameraInput()
+    inp.mouse_x, inp.mouse_y = cam.last_mouse_x, cam.last_mouse_y
+    for k, v in keys.items():
+        setattr(inp, k, v)
+    rtmi.abi.load().rtmi_camera_update(C.byref(cam), dt, C.byref(inp))
+
+
+def test_camera_defaults_and_motion(rtmi):
+    cam = rtmi.make_camera(1280, 720)
+    assert list(cam.position) == [0.0, 1.0, -1.0] and cam.yaw == -90.0 and cam.pitch == 0.0 and cam.moved == 0
+    assert np.allclose(cam.forward[:], [0.0, 0.0, -1.0], atol=1e-6)
+    assert np.allclose(cam.right[:], [1.0, 0.0, 0.0], atol=1e-6)   # cross(forward, up)
+    _update(rtmi, cam)
+    assert cam.moved == 0 and list(cam.position) == [0.0, 1.0, -1.0]
+    # W moves along -forward (CameraFPS.cpp:62), speed 2, dt 0.5 -> +1 in z
+    _update(rtmi, cam, key_w=1)
+    assert cam.moved == 1 and np.allclose(cam.position[:], [0.0, 1.0, 0.0], atol=1e-6)
+    _update(rtmi, cam, key_s=1, key_f=1)                            # speed 10
+    assert np.allclose(cam.position[:], [0.0, 1.0, -5.0], atol=1e-5)
+    _update(rtmi, cam, key_a=1, key_c=1)                            # A = +right, speed 0.5
+    assert np.allclose(cam.position[:], [0.25, 1.0, -5.0], atol=1e-5)
+    _update(rtmi, cam, key_d=1, key_space=1)                        # D = -right, space = +y (not normalised together)
+    assert np.allclose(cam.position[:], [-0.75, 2.0, -5.0], atol=1e-5)
+    _update(rtmi, cam, key_left_shift=1)
+    assert np.allclose(cam.position[:], [-0.75, 1.0, -5.0], atol=1e-5)
+    # the view follows the position
+    iv = np.array(cam.inverse_view[:]).reshape(4, 4).T
+    assert np.allclose(iv[:3, 3], cam.position[:], atol=1e-5)
+    _update(rtmi, cam)
+    assert cam.moved == 0
+
+
+def test_camera_mouse_look(rtmi):
+    cam = rtmi.make_camera(640, 360)
+    inp = rtmi.abi.CameraInput()
+    inp.mouse_x, inp.mouse_y, inp.mouse_button_2 = 50.0, 1000.0, 0
+    rtmi.abi.load().rtmi_camera_update(C.byref(cam), 0.1, C.byref(inp))
+    assert cam.moved == 0 and cam.yaw == -90.0            # button up: only the cursor is remembered
+    inp.mouse_x, inp.mouse_y, inp.mouse_button_2 = 150.0, 2000.0, 1
+    rtmi.abi.load().rtmi_camera_update(C.byref(cam), 0.1, C.byref(inp))
+    assert cam.moved == 1 and abs(cam.yaw - (-70.0)) < 1e-4 and cam.pitch == 89.0   # +100 px * 0.2, pitch clamped
+    f = [math.cos(math.radians(-70.0)) * math.cos(math.radians(89.0)), math.sin(math.radians(89.0)),
+         math.sin(math.radians(-70.0)) * math.cos(math.radians(89.0))]
+    assert np.allclose(cam.forward[:], f, atol=1e-5)
+    inp.mouse_x = 150.0 + 5 * 360 * 5                     # yaw wraps with fmod
+    rtmi.abi.load().rtmi_camera_update(C.byref(cam), 0.1, C.byref(inp))
+    assert abs(cam.yaw - 290.0) < 1e-2                     # fmod(-70 + 1800, 360), same direction as -70
+    assert np.allclose(cam.forward[:], f, atol=1e-4)
+
+
+def test_frame_policy(rtmi):
+    lib = rtmi.abi.load()
+    cam = rtmi.make_camera(320, 180)
+    fd = rtmi.abi.FrameData()
+    lib.rtmi_default_frame_data(C.byref(fd))
+    seen = []
+    for step in range(8):
+        _update(rtmi, cam, key_w=1 if step == 4 else 0)
+        lib.rtmi_frame_advance(C.byref(fd), C.byref(cam), 1 if step == 6 else 0)
+        seen.append(fd.frame_index)
+    # ++ each frame, 1 when the camera moved, Q zeroes it so the next value is 1
+    assert seen == [1, 2, 3, 4, 1, 2, 1, 2]
+    assert list(fd.window) == [320.0, 180.0] and fd.camera_pos[3] == 0.0
+
+
+def test_ppm_and_pfm_writers(rtmi, tmp_path):
+    lib = rtmi.abi.load()
+    w, h = 3, 2
+    img = np.zeros((h, w, 4), dtype=np.uint8)
+    img[0, :, 0] = [10, 20, 30]       # buffer row 0 = bottom of the view
+    img[1, :, 1] = [100, 150, 200]
+    p = tmp_path / "a.ppm"
+    assert lib.rtmi_write_ppm(str(p).encode(), img.ctypes.data, w, h, 0) == 0
+    raw = p.read_bytes()
+    assert raw.startswith(b"P6\n3 2\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n3 2\n255\n"):], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(px[0, :, 1], [100, 150, 200]) and np.array_equal(px[1, :, 0], [10, 20, 30])
+    assert lib.rtmi_write_ppm(str(p).encode(), img.ctypes.data, w, h, 1) == 0
+    px = np.frombuffer(p.read_bytes()[len(b"P6\n3 2\n255\n"):], dtype=np.uint8).reshape(h, w, 3)
+
+    def srgb(v):
+        c = v / 255.0
+        s = 12.92 * c if c <= 0.0031308 else 1.055 * c ** (1 / 2.4) - 0.055
+        return int(round(s * 255))
+    assert list(px[0, :, 1]) == [srgb(100), srgb(150), srgb(200)] and px[0, 0, 0] == 0
+    acc = np.arange(h * w * 4, dtype=np.float32).reshape(h, w, 4)
+    q = tmp_path / "a.pfm"
+    assert lib.rtmi_write_pfm(str(q).encode(), acc.ctypes.data, w, h, 4) == 0
+    raw = q.read_bytes()
+    head = b"PF\n3 2\n-1.0\n"
+    assert raw.startswith(head)
+    data = np.frombuffer(raw[len(head):], dtype="<f4").reshape(h, w, 3)
+    assert np.array_equal(data, acc[..., :3] / 4.0)
+    assert lib.rtmi_write_ppm(b"/nonexistent_dir/x.ppm", img.ctypes.data, w, h, 0) == rtmi.abi.ERR_IO
