@@ -97,7 +97,9 @@ typedef enum rtmi_status {
 typedef enum rtmi_variant {
     RTMI_VARIANT_MEGAKERNEL = 0,   /* one lane per pixel, frame / sample / bounce loops nested as in RT.comp:464-468, 413 */
     RTMI_VARIANT_REGENERATE = 1,   /* one lane per pixel, single segment loop; a lane that ends a path starts its next one */
-    RTMI_VARIANT_WAVEFRONT  = 2    /* queued segments with ballot/prefix-sum compaction between bounces */
+    RTMI_VARIANT_COMPACT    = 2    /* default: the primary segment (identical for every sample of a pixel, RT.comp:449-453)
+                                      is evaluated once per launch; pixels that see only sky are finished at once, the
+                                      others are stream-compacted (wave ballot + prefix count) and traced by dense waves */
 } rtmi_variant;
 
 /* Event counters (uint64 each), index = rtmi_counter.  Same events the CPU oracle counts. */
@@ -192,6 +194,12 @@ RTMI_API int rtmi_reset_counters(rtmi_ctx *ctx);
  * for n inputs.  op: 0 1/x, 1 sqrt, 2 log2 (library polynomial), 3 exp2 (library polynomial),
  * 4 uint32 -> float scaled by 2^-32 (input reinterpreted as uint32), 5 pow(x, y), 6 x / y. */
 RTMI_API int rtmi_selftest_math(rtmi_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
+/* ClosestHit (RT.comp:338-388) of n arbitrary rays (3 floats each) against the uploaded scene, using
+ * the first sphere_number spheres and mesh_number meshes: ray parameter t (FLT_MAX on a miss) and
+ * primitive id per ray.  A test hook for analytic and corner-case rays. */
+RTMI_API int rtmi_selftest_closest_hit(rtmi_ctx *ctx, uint32_t sphere_number, uint32_t mesh_number,
+                                       const float *origins, const float *directions, size_t n,
+                                       float *t_out, uint32_t *prim_out);
 
 /* ------------------------------------------------------------------------------------------
  * Host side kept from the reference (C wrappers over the C++ classes of the same names).

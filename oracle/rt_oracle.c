@@ -355,6 +355,24 @@ static hit_info closest_hit(const orc_frame_data *fd, v3 o, v3 d,
     return best;
 }
 
+/* ClosestHit of n arbitrary rays: t (FLT_MAX on a miss) and primitive id per ray */
+void orc_closest_hit(uint32_t sphere_count, uint32_t mesh_count,
+                     const orc_sphere *spheres, const orc_triangle *tris, const orc_mesh *meshes,
+                     const float *origins, const float *dirs, size_t n, float *t_out, uint32_t *prim_out)
+{
+    orc_frame_data fd;
+    memset(&fd, 0, sizeof fd);
+    fd.sphere_count = sphere_count;
+    fd.mesh_count = mesh_count;
+    counters_t cn;
+    memset(&cn, 0, sizeof cn);
+    for (size_t i = 0; i < n; i++) {
+        hit_info h = closest_hit(&fd, v3_from(origins + 3 * i), v3_from(dirs + 3 * i), spheres, tris, meshes, &cn);
+        t_out[i] = h.dist;
+        prim_out[i] = h.prim;
+    }
+}
+
 /* Raytracing.comp:390-406.  Note the .xzy swizzle of the sun direction and the raw (not
  * normalised) ray direction. */
 static v3 env_light(const orc_frame_data *fd, v3 d)
@@ -482,20 +500,23 @@ int orc_render_rows(const orc_frame_data *fd_in,
                 float of[3], df[3];
                 orc_primary_ray(&fd, x, y, of, df);
                 v3 o = v3_from(of), d = v3_from(df);
-                uint32_t hash = 2166136261u, first = ORC_MISS_ID, rng = 0;
+                uint32_t hash = 0u, first = ORC_MISS_ID, rng = 0;
                 float sum[3] = { accum[4 * px + 0], accum[4 * px + 1], accum[4 * px + 2] };
                 uint32_t fi = first_frame;
                 for (uint32_t f = 0; f < n_frames; f++) {
                     fi = first_frame + f;
                     v3 light = v3_make(0.0f, 0.0f, 0.0f);
                     rng = orc_pixel_seed(x, y, fd.window[0], fi);
+                    /* the frame's own hash: ids of all its segments in order, keyed by the frame index */
+                    uint32_t frame_hash = 2166136261u ^ (fi * 0x9E3779B9u);
                     for (uint32_t k = 0; k < fd.rays_per_pixel; k++) {
                         rng += k;
                         uint32_t fp = ORC_MISS_ID;
-                        v3 l = trace(&fd, o, d, &rng, spheres, tris, meshes, &cn, &hash, &fp);
+                        v3 l = trace(&fd, o, d, &rng, spheres, tris, meshes, &cn, &frame_hash, &fp);
                         if (k == 0) first = fp;
                         light = v3_add(light, l);
                     }
+                    hash += frame_hash;
                     float rpp = (float)fd.rays_per_pixel;
                     light = v3_make(light.x / rpp, light.y / rpp, light.z / rpp);
                     cn.c[ORC_N_PIXEL_FRAMES]++;

@@ -91,6 +91,12 @@ int orc_ray_triangle(const float o[3], const float d[3], const orc_triangle *tri
                      float *t, float pos[3], float nrm[3]);
 int orc_ray_box(const float o[3], const float d[3], const float lo[3], const float hi[3]);
 
+/* ClosestHit (Raytracing.comp:338-388) of n arbitrary rays against the first sphere_count spheres and
+ * mesh_count meshes: ray parameter (FLT_MAX on a miss) and primitive id per ray. */
+void orc_closest_hit(uint32_t sphere_count, uint32_t mesh_count,
+                     const orc_sphere *spheres, const orc_triangle *tris, const orc_mesh *meshes,
+                     const float *origins, const float *dirs, size_t n, float *t_out, uint32_t *prim_out);
+
 /* Sky: Raytracing.comp:390-406 */
 void  orc_env_light(const orc_frame_data *fd, const float d[3], float rgb[3]);
 float orc_pow(float x, float y);
@@ -127,7 +133,9 @@ void orc_default_frame_constants(orc_frame_data *fd);
  *   out_rgba8  : display image of the LAST frame (sum / frameIndex -> UNORM8, alpha 255)
  *   prim_id    : closest-hit primitive id of the FIRST segment of the first path of the LAST frame
  *                (sphere i -> i; triangle j -> sphere_count + j; miss -> ORC_MISS_ID)
- *   chain_hash : per pixel FNV-style hash over every segment's primitive id, all frames in the call
+ *   chain_hash : per pixel, the sum (mod 2^32) over the frames of the call of each frame's hash: an
+ *                FNV-style fold (h = (h ^ id) * 16777619) over the primitive ids of all the frame's
+ *                segments in order, started at 2166136261 ^ (frame_index * 0x9E3779B9)
  *   rng_state  : per pixel RNG state after the LAST frame
  *   counters   : ORC_N_COUNTERS uint64 event totals (added to)
  */

@@ -17,7 +17,7 @@ MISS_ID = 0xFFFFFFFF
 
 VARIANT_MEGAKERNEL = 0
 VARIANT_REGENERATE = 1
-VARIANT_WAVEFRONT = 2
+VARIANT_COMPACT = 2
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -117,6 +117,8 @@ PROTOTYPES = {
     "rtmi_get_counters": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "rtmi_reset_counters": (C.c_int, [_ctx]),
     "rtmi_selftest_math": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rtmi_selftest_closest_hit": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p]),
     "rtmi_load_model": (C.c_int, [C.c_char_p, C.POINTER(Triangle), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Mesh), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Material), _f, _f, C.c_int]),

@@ -59,24 +59,21 @@ __device__ __forceinline__ float smoothstep(float e0, float e1, float x)
 
 // ---- pow(x, y) = exp2(y * log2(x)) with fixed polynomials (coefficients: the public-domain Cephes
 // single-precision log / exp2 fits).  Step for step the same sequence as the CPU checker uses.
-__device__ __forceinline__ float log2_poly(float x)
+// Both are written without branches: the polynomial runs on every input (special inputs are first
+// replaced by a harmless in-range value) and the defined results for NaN, negative, zero, infinite
+// and out-of-range arguments are selected at the end.
+__device__ __forceinline__ float log2_poly(float x0)
 {
-    if (!(x == x)) return x;
-    if (x < 0.0f) return __uint_as_float(0x7FC00000u);
-    if (x == 0.0f) return __uint_as_float(0xFF800000u);
-    if (x == __uint_as_float(0x7F800000u)) return x;
-    int e = 0;
-    if (x < __uint_as_float(0x00800000u)) {
-        x = x * 16777216.0f;
-        e = -24;
-    }
+    const float inf = __uint_as_float(0x7F800000u);
+    const bool is_den = x0 < __uint_as_float(0x00800000u);
+    float x = is_den ? x0 * 16777216.0f : x0;
+    int e = is_den ? -24 : 0;
     uint32_t b = __float_as_uint(x);
     e += (int)((b >> 23) & 0xFFu) - 127;
     float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
-    if (m > 1.41421356237f) {
-        m = m * 0.5f;
-        e += 1;
-    }
+    const bool big = m > 1.41421356237f;
+    m = big ? m * 0.5f : m;
+    e += big ? 1 : 0;
     float f = m - 1.0f;
     float z = f * f;
     float p = 7.0376836292e-2f;
@@ -95,21 +92,23 @@ __device__ __forceinline__ float log2_poly(float x)
     r = r + y;
     r = r + f;
     r = r + (float)e;
+    r = (x0 == inf) ? x0 : r;
+    r = (x0 == 0.0f) ? -inf : r;
+    r = (x0 < 0.0f) ? __uint_as_float(0x7FC00000u) : r;
+    r = (x0 == x0) ? r : x0;
     return r;
 }
 
-__device__ __forceinline__ float exp2_poly(float x)
+__device__ __forceinline__ float exp2_poly(float x0)
 {
-    if (!(x == x)) return x;
-    if (x > 128.0f) return __uint_as_float(0x7F800000u);
-    if (x < -150.0f) return 0.0f;
+    const bool is_nan = !(x0 == x0), too_big = x0 > 128.0f, too_small = x0 < -150.0f;
+    const float x = (is_nan || too_big || too_small) ? 0.0f : x0;
     float fl = floorf(x);
     int n = (int)fl;
     float r = x - fl;
-    if (r > 0.5f) {
-        n += 1;
-        r = r - 1.0f;
-    }
+    const bool up = r > 0.5f;
+    n += up ? 1 : 0;
+    r = up ? r - 1.0f : r;
     float p = 1.535336188319500e-4f;
     p = p * r + 1.339887440266574e-3f;
     p = p * r + 9.618437357674640e-3f;
@@ -117,22 +116,24 @@ __device__ __forceinline__ float exp2_poly(float x)
     p = p * r + 2.402264791363012e-1f;
     p = p * r + 6.931472028550421e-1f;
     p = p * r + 1.0f;
-    if (n > 127) {
-        p = p * __uint_as_float(0x7F000000u);
-        n -= 127;
-    }
-    if (n < -126) {
-        p = p * __uint_as_float(0x00800000u);
-        n += 126;
-    }
-    if (n < -126) n = -126;
-    return p * __uint_as_float((uint32_t)(n + 127) << 23);
+    const bool hi = n > 127;
+    p = hi ? p * __uint_as_float(0x7F000000u) : p;
+    n = hi ? n - 127 : n;
+    const bool lo = n < -126;
+    p = lo ? p * __uint_as_float(0x00800000u) : p;
+    n = lo ? n + 126 : n;
+    n = n < -126 ? -126 : n;
+    float res = p * __uint_as_float((uint32_t)(n + 127) << 23);
+    res = too_small ? 0.0f : res;
+    res = too_big ? __uint_as_float(0x7F800000u) : res;
+    res = is_nan ? x0 : res;
+    return res;
 }
 
 __device__ __forceinline__ float pow_poly(float x, float y)
 {
-    if (x == 0.0f && y > 0.0f) return 0.0f;
-    return exp2_poly(y * log2_poly(x));
+    const float r = exp2_poly(y * log2_poly(x));
+    return (x == 0.0f && y > 0.0f) ? 0.0f : r;
 }
 
 // ---- RNG (Raytracing.comp:106-112).  The shader divides by the literal 4294967295.0, which is
@@ -164,6 +165,19 @@ struct DeviceScene {
     uint32_t n_spheres, n_triangles, n_meshes;
 };
 
+// Fetch of a record whose index is the same in every lane.  The scene arrays are never written by a
+// kernel that reads them, so they may be read through the constant address space, which lets the
+// compiler use one scalar load (s_load_dwordx4) into SGPRs whatever other memory traffic the kernel has.
+__device__ __forceinline__ float4 ld_uniform(const float4 *base, uint32_t index)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v = ((const __attribute__((address_space(4))) f32x4 *)base)[index];
+#pragma clang diagnostic pop
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct Hit {
     float t;
     uint32_t prim;  // kMissId when nothing was hit
@@ -189,25 +203,66 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
     best.u = 0.0f;
     best.v = 0.0f;
 
-    // RaySphere, Raytracing.comp:130-161
+    // RaySphere, Raytracing.comp:130-161.  Every sphere's root is numer / (2a) with the same
+    // positive denominator, and a correctly rounded divide is monotonic in its numerator, so the
+    // closest sphere is found by comparing numerators and only the winner is divided.  The three
+    // places where a numerator comparison could disagree with the comparison of the rounded
+    // quotients (root within 1e-5 relative of the 0.0001 threshold, two candidates within 1e-5
+    // relative of each other, denominator or quotient outside the normal range) are detected and
+    // sent through the literal per-sphere evaluation below, so the outcome is always the one the
+    // shader's own sequence gives.
     if (n_spheres > 0) {
         const float a = dot(d, d);
         const float a4 = 4.0f * a;
         const float a2 = 2.0f * a;
+        const float thr = 0.0001f * a2;
+        const float thr_lo = thr * 0.99999f, thr_hi = thr * 1.00001f;
+        float best_n = __uint_as_float(0x7F800000u);
+        uint32_t best_i = kMissId;
+        bool ambiguous = !(a2 > 9.094947e-13f && a2 < 1.0995116e12f);  // 2^-40 .. 2^40
         for (uint32_t i = 0; i < n_spheres; i++) {
-            const float4 g = sc.sphere_geom[i];
+            const float4 g = ld_uniform(sc.sphere_geom, i);
             V3 oc = o - mk(g.x, g.y, g.z);
             float b = 2.0f * dot(oc, d);
             float c = dot(oc, oc) - g.w;
             float disc = b * b - a4 * c;
-            if (COUNT) cn.c[0]++;
-            if (disc >= 0.0f) {
-                if (COUNT) cn.c[1]++;
-                float t = (-b - sqrtf(disc)) / a2;
-                if (t > 0.0001f && t < best.t) {
-                    best.t = t;
-                    best.prim = i;
-                    best.mat = i;
+            if (COUNT) {
+                cn.c[0]++;
+                if (disc >= 0.0f) cn.c[1]++;
+            }
+            // b >= 0 makes the numerator -b - sqrt(disc) <= 0, which can never pass t > 0.0001
+            if (disc >= 0.0f && b < 0.0f) {
+                const float n = -b - sqrtf(disc);
+                if (n > thr_lo && n < best_n) {
+                    ambiguous = ambiguous || (n < thr_hi) || (n > best_n * 0.99999f);
+                    best_n = n;
+                    best_i = i;
+                }
+            }
+        }
+        if (best_i != kMissId) {
+            best.t = best_n / a2;
+            best.prim = best_i;
+            best.mat = best_i;
+            ambiguous = ambiguous || !(best.t < kFltMax);
+        }
+        if (ambiguous) {
+            // literal evaluation order of the shader, one divide per sphere
+            best.t = kFltMax;
+            best.prim = kMissId;
+            for (uint32_t i = 0; i < n_spheres; i++) {
+                const float4 g = ld_uniform(sc.sphere_geom, i);
+                V3 oc = o - mk(g.x, g.y, g.z);
+                float b = 2.0f * dot(oc, d);
+                float c = dot(oc, oc) - g.w;
+                float disc = b * b - a4 * c;
+                if (disc >= 0.0f) {
+                    float t = (-b - sqrtf(disc)) / a2;
+                    if (t > 0.0001f && t < best.t) {
+                        best.t = t;
+                        best.prim = i;
+                        best.mat = i;
+                    }
                 }
             }
         }
@@ -217,8 +272,8 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
     if (n_meshes > 0) {
         const float fx = 1.0f / d.x, fy = 1.0f / d.y, fz = 1.0f / d.z;
         for (uint32_t m = 0; m < n_meshes; m++) {
-            const float4 lo = sc.mesh_box[2 * m + 0];
-            const float4 hi = sc.mesh_box[2 * m + 1];
+            const float4 lo = ld_uniform(sc.mesh_box, 2 * m + 0);
+            const float4 hi = ld_uniform(sc.mesh_box, 2 * m + 1);
             float t1 = (lo.x - o.x) * fx;
             float t2 = (hi.x - o.x) * fx;
             float t3 = (lo.y - o.y) * fy;
@@ -233,13 +288,13 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
                 const uint32_t start = __float_as_uint(lo.w);
                 const uint32_t count = __float_as_uint(hi.w);
                 for (uint32_t j = start; j < start + count; j++) {
-                    const float4 P = sc.tri_isect[4 * j + 0];
-                    const float4 N = sc.tri_isect[4 * j + 3];
+                    const float4 P = ld_uniform(sc.tri_isect, 4 * j + 0);
+                    const float4 N = ld_uniform(sc.tri_isect, 4 * j + 3);
                     if (COUNT) cn.c[4]++;
                     float det = -dot(d, mk(N.x, N.y, N.z));
                     if (det >= 1e-6f) {
-                        const float4 AB = sc.tri_isect[4 * j + 1];
-                        const float4 AC = sc.tri_isect[4 * j + 2];
+                        const float4 AB = ld_uniform(sc.tri_isect, 4 * j + 1);
+                        const float4 AC = ld_uniform(sc.tri_isect, 4 * j + 2);
                         V3 ao = o - mk(P.x, P.y, P.z);
                         V3 dao = cross(ao, d);
                         float inv = 1.0f / det;

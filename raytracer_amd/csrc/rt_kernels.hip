@@ -1,8 +1,22 @@
 // rt_kernels.hip — gfx950 kernels for the path-tracing dispatch (Raytracing.comp:441-481) and
-// their launchers.  One lane owns one pixel for the whole launch; a wave covers an 8x8 pixel tile
-// and a 256-thread workgroup a 16x16 tile, so the float4 accumulation rows a wave touches are
-// whole 128-byte lines.  The running sum of a pixel lives in registers across all frames of a
-// launch and goes to HBM once.
+// their launchers.  One lane owns one pixel for a whole launch and keeps the pixel's running sum in
+// registers across all frames of the launch, so the float4 accumulation image is read and written
+// once per launch instead of once per frame.
+//
+// Three variants, all bit-identical in every output:
+//   k_megakernel   loops nested as the shader nests them (frames, samples, bounces);
+//   k_regenerate   the three loops flattened into one loop over segments (a lane that ends a path
+//                  starts its next one at once);
+//   k_classify + k_paths
+//                  the shader casts the same primary ray for every sample of a pixel (no jitter,
+//                  Raytracing.comp:449-453), so a pixel's first closest-hit is evaluated once per
+//                  launch instead of once per path.  k_classify finishes pixels whose primary ray
+//                  leaves the scene (their whole path is the same every frame) and stream-compacts
+//                  the others with a wave ballot + prefix count; k_paths traces them: each wave owns 64
+//                  compacted pixels and its lanes share all (pixel, frame) work items of those pixels,
+//                  a lane that finishes an item taking the wave's next one, while per-frame results
+//                  pass through a small LDS ring so that every pixel's sum is still formed in frame
+//                  order.
 #include "rt_kernels.hpp"
 
 #include "rt_device.hpp"
@@ -15,6 +29,11 @@ namespace {
 
 constexpr int kBlockThreads = 256;
 constexpr int kTile = 16;
+constexpr uint32_t kHashInit = 2166136261u, kHashPrime = 16777619u, kHashFrameKey = 0x9E3779B9u;
+
+// Validation hash of a pixel: sum over frames of each frame's own fold of its segment ids, started
+// from a value keyed by the frame index.  A sum so that frames may be finished in any order.
+__device__ __forceinline__ uint32_t frame_hash_init(uint32_t frame_index) { return kHashInit ^ (frame_index * kHashFrameKey); }
 
 struct PixelSetup {
     uint32_t x, y;
@@ -23,18 +42,16 @@ struct PixelSetup {
     float lin;  // float(x) + width * float(y), the float part of the seed (Raytracing.comp:462)
 };
 
-__device__ __forceinline__ PixelSetup pixel_setup(const RenderParams &p)
+// Raytracing.comp:446-453 and the float part of :462 for pixel (x, y)
+__device__ __forceinline__ PixelSetup pixel_setup_xy(const RenderParams &p, uint32_t x, uint32_t y, bool in_range)
 {
     PixelSetup s;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    s.x = blockIdx.x * kTile + (wave & 1u) * 8u + (lane & 7u);
-    s.y = blockIdx.y * kTile + (wave >> 1) * 8u + (lane >> 3);
-    s.in_range = s.x < p.width && s.y < p.height;
+    s.x = x;
+    s.y = y;
+    s.in_range = in_range;
     const float fw = p.window_w, fh = p.window_h;
-    // Raytracing.comp:449-453
-    const float cx = ((float)s.x / fw) * 2.0f - 1.0f;
-    const float cy = ((float)s.y / fh) * 2.0f - 1.0f;
+    const float cx = ((float)x / fw) * 2.0f - 1.0f;
+    const float cy = ((float)y / fh) * 2.0f - 1.0f;
     const float *ip = p.inv_proj;
     float tx = ip[0] * cx + ip[4] * cy + ip[8] * 1.0f + ip[12] * 1.0f;
     float ty = ip[1] * cx + ip[5] * cy + ip[9] * 1.0f + ip[13] * 1.0f;
@@ -46,8 +63,18 @@ __device__ __forceinline__ PixelSetup pixel_setup(const RenderParams &p)
     s.dir.y = iv[1] * n.x + iv[5] * n.y + iv[9] * n.z + iv[13] * 0.0f;
     s.dir.z = iv[2] * n.x + iv[6] * n.y + iv[10] * n.z + iv[14] * 0.0f;
     s.origin = mk(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    s.lin = (float)s.x + fw * (float)s.y;
+    s.lin = (float)x + fw * (float)y;
     return s;
+}
+
+// 16x16 pixel tile per workgroup, 8x8 per wave: the float4 rows a wave touches are whole 128-byte lines
+__device__ __forceinline__ PixelSetup pixel_setup(const RenderParams &p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * kTile + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = blockIdx.y * kTile + (wave >> 1) * 8u + (lane >> 3);
+    return pixel_setup_xy(p, x, y, x < p.width && y < p.height);
 }
 
 __device__ __forceinline__ Sky make_sky(const RenderParams &p)
@@ -71,22 +98,32 @@ __device__ __forceinline__ V3 average_samples(V3 l, const RenderParams &p)
     return mk(l.x / r, l.y / r, l.z / r);
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-template <bool VALIDATE>
-__device__ __forceinline__ void finish_pixel(const RenderParams &p, const PixelSetup &s, V3 sum, uint32_t last_frame,
-                                             uint32_t first_prim, uint32_t hash, uint32_t rng, Counters &cn)
+__device__ __forceinline__ void zero(Counters &c)
 {
-    if (s.in_range) {
-        const size_t px = (size_t)s.y * p.width + s.x;
+#pragma unroll
+    for (int i = 0; i < 11; i++) c.c[i] = 0u;
+}
+
+// Store one finished pixel (Raytracing.comp:479-480) and, in validating builds, its check values;
+// then fold the wave's event counters into the global totals.  Every lane of the wave must call it.
+// cn holds events counted one by one; per_path holds the events of one cached primary segment, which
+// the shader would have repeated for each of the pixel's n_paths paths.
+template <bool VALIDATE>
+__device__ __forceinline__ void finish_pixel(const RenderParams &p, uint32_t x, uint32_t y, bool write, V3 sum,
+                                             uint32_t first_prim, uint32_t hash, uint32_t rng, const Counters &cn,
+                                             const Counters &per_path, uint32_t n_paths)
+{
+    if (write) {
+        const size_t px = (size_t)y * p.width + x;
         p.accum[px] = make_float4(sum.x, sum.y, sum.z, 1.0f);
-        // Raytracing.comp:480: display = sum / frameIndex, stored to the rgba8 image
-        const float div = (float)last_frame;
+        const float div = (float)(p.first_frame + p.n_frames - 1u);
         const uint32_t r = unorm8(sum.x / div), g = unorm8(sum.y / div), b = unorm8(sum.z / div);
         p.out_rgba8[px] = r | (g << 8) | (b << 16) | 0xFF000000u;
         if (VALIDATE) {
@@ -96,18 +133,28 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &p, const PixelS
         }
     }
     if (VALIDATE) {
-        // lanes outside the image hold zero counters
 #pragma unroll
         for (int i = 0; i < 11; i++) {
-            const uint32_t tot = wave_sum(s.in_range ? cn.c[i] : 0u);
-            if ((threadIdx.x & 63u) == 0u && tot != 0u) atomicAdd(&p.counters[i], (unsigned long long)tot);
+            // cn counts what this lane did (for any pixel); per_path belongs to the pixel the lane writes
+            const unsigned long long mine = (unsigned long long)cn.c[i] + (write ? (unsigned long long)per_path.c[i] * n_paths : 0ull);
+            const unsigned long long tot = wave_sum(mine);
+            if ((threadIdx.x & 63u) == 0u && tot != 0ull) atomicAdd(&p.counters[i], tot);
         }
     }
 }
 
+__device__ __forceinline__ V3 load_sum(const RenderParams &p, uint32_t x, uint32_t y, bool in_range)
+{
+    // frame_index == 1 overwrites, so the old contents are only needed otherwise (Raytracing.comp:471-477)
+    if (in_range && p.first_frame != 1u) {
+        const float4 a = p.accum[(size_t)y * p.width + x];
+        return mk(a.x, a.y, a.z);
+    }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
 // --------------------------------------------------------------------------------------------
-// Variant 0: loops nested exactly as the shader nests them (frames of the launch, samples of a
-// frame, bounces of a path).
+// Variant 0: loops nested exactly as the shader nests them.
 // --------------------------------------------------------------------------------------------
 template <bool VALIDATE>
 __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams p)
@@ -116,22 +163,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
     const Sky sky = make_sky(p);
     const DeviceScene &sc = p.scene;
     const uint32_t nS = p.sphere_number, nM = p.mesh_number;
-    Counters cn;
-    if (VALIDATE) {
-#pragma unroll
-        for (int i = 0; i < 11; i++) cn.c[i] = 0u;
-    }
-    uint32_t hash = 2166136261u, first_prim = kMissId, rng = 0u;
+    Counters cn, none;
+    zero(cn);
+    zero(none);
+    uint32_t hash = 0u, first_prim = kMissId, rng = 0u;
 
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    if (s.in_range && !(p.first_frame == 1u)) {
-        const float4 a = p.accum[(size_t)s.y * p.width + s.x];
-        sum = mk(a.x, a.y, a.z);
-    }
+    V3 sum = load_sum(p, s.x, s.y, s.in_range);
     if (s.in_range) {
         for (uint32_t f = 0; f < p.n_frames; f++) {
             const uint32_t fi = p.first_frame + f;
             rng = (uint32_t)s.lin + fi * 719393u;
+            uint32_t fh = frame_hash_init(fi);
             V3 frame_light = mk(0.0f, 0.0f, 0.0f);
             for (uint32_t k = 0; k < p.rays_per_pixel; k++) {
                 rng += k;
@@ -142,7 +184,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
                     const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
                     if (VALIDATE) {
                         cn.c[10]++;
-                        hash = (hash ^ h.prim) * 16777619u;
+                        fh = (fh ^ h.prim) * kHashPrime;
                         if (i == 0 && k == 0) first_prim = h.prim;
                     }
                     if (h.prim != kMissId) {
@@ -161,19 +203,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
                 frame_light = frame_light + light;
             }
             frame_light = average_samples(frame_light, p);
-            if (VALIDATE) cn.c[8]++;
-            // Raytracing.comp:471-477
+            if (VALIDATE) {
+                cn.c[8]++;
+                hash += fh;
+            }
             sum = (fi == 1u) ? frame_light : sum + frame_light;
         }
     }
-    finish_pixel<VALIDATE>(p, s, sum, p.first_frame + p.n_frames - 1u, first_prim, hash, rng, cn);
+    finish_pixel<VALIDATE>(p, s.x, s.y, s.in_range, sum, first_prim, hash, rng, cn, none, 0u);
 }
 
 // --------------------------------------------------------------------------------------------
-// Variant 1: the three loops flattened into one loop over segments.  A lane whose path ends
-// (miss or bounce limit) starts its own next path in the same iteration slot, so lanes of a wave
-// stay busy until their pixel has no frames left; the order of every pixel's operations, and so
-// every bit of its result, is unchanged.
+// Variant 1: one loop over segments; lanes regenerate their own next path.
 // --------------------------------------------------------------------------------------------
 template <bool VALIDATE>
 __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams p)
@@ -182,18 +223,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
     const Sky sky = make_sky(p);
     const DeviceScene &sc = p.scene;
     const uint32_t nS = p.sphere_number, nM = p.mesh_number;
-    Counters cn;
-    if (VALIDATE) {
-#pragma unroll
-        for (int i = 0; i < 11; i++) cn.c[i] = 0u;
-    }
-    uint32_t hash = 2166136261u, first_prim = kMissId;
+    Counters cn, none;
+    zero(cn);
+    zero(none);
+    uint32_t hash = 0u, first_prim = kMissId;
+    uint32_t fh = frame_hash_init(p.first_frame);
 
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    if (s.in_range && !(p.first_frame == 1u)) {
-        const float4 a = p.accum[(size_t)s.y * p.width + s.x];
-        sum = mk(a.x, a.y, a.z);
-    }
+    V3 sum = load_sum(p, s.x, s.y, s.in_range);
 
     // per-lane cursor: frame f (0-based within the launch), sample k, bounce i
     uint32_t f = 0, k = 0, i = 0;
@@ -208,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
         const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
         if (VALIDATE) {
             cn.c[10]++;
-            hash = (hash ^ h.prim) * 16777619u;
+            fh = (fh ^ h.prim) * kHashPrime;
             if (i == 0 && k == 0) first_prim = h.prim;
         }
         bool path_done;
@@ -231,7 +267,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
             k++;
             if (k >= p.rays_per_pixel) {
                 frame_light = average_samples(frame_light, p);
-                if (VALIDATE) cn.c[8]++;
+                if (VALIDATE) {
+                    cn.c[8]++;
+                    hash += fh;
+                    fh = frame_hash_init(p.first_frame + f + 1u);
+                }
                 const uint32_t fi = p.first_frame + f;
                 sum = (fi == 1u) ? frame_light : sum + frame_light;
                 frame_light = mk(0.0f, 0.0f, 0.0f);
@@ -252,7 +292,281 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
             }
         }
     }
-    finish_pixel<VALIDATE>(p, s, sum, p.first_frame + p.n_frames - 1u, first_prim, hash, rng, cn);
+    finish_pixel<VALIDATE>(p, s.x, s.y, s.in_range, sum, first_prim, hash, rng, cn, none, 0u);
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant 2, first kernel: evaluate every pixel's primary segment once.  A pixel whose primary ray
+// hits nothing gets the same radiance every frame (one sky evaluation, no random numbers), so it is
+// finished here with the frame-by-frame additions the shader would have made.  Pixels that hit are
+// appended to hit_list: the wave ballots its hit lanes, one lane reserves popcount slots with a single
+// atomic, and each hit lane takes the slot given by the count of hit lanes below it.
+// --------------------------------------------------------------------------------------------
+template <bool VALIDATE>
+__global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p)
+{
+    const PixelSetup s = pixel_setup(p);
+    const DeviceScene &sc = p.scene;
+    const uint32_t nS = p.sphere_number, nM = p.mesh_number;
+    Counters seg, none;
+    zero(seg);
+    zero(none);
+
+    bool hit = false;
+    if (s.in_range) {
+        const Hit h0 = closest_hit<VALIDATE>(sc, nS, nM, s.origin, s.dir, seg);
+        hit = h0.prim != kMissId;
+    }
+
+    const unsigned long long mask = __ballot(hit);
+    if (mask != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(p.hit_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, (int)leader, 64);
+        if (hit) p.hit_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = s.y * p.width + s.x;
+    }
+
+    const bool sky_pixel = s.in_range && !hit;
+    V3 sum = load_sum(p, s.x, s.y, sky_pixel);
+    uint32_t hash = 0u, rng = 0u;
+    const uint32_t n_paths = p.n_frames * p.rays_per_pixel;
+    if (sky_pixel) {
+        const Sky sky = make_sky(p);
+        // Trace(): incomingLight = 0 + env * rayColor(1,1,1), Raytracing.comp:410-411, 434
+        const V3 light = mk(0.0f, 0.0f, 0.0f) + env_light(sky, s.dir) * mk(1.0f, 1.0f, 1.0f);
+        V3 frame_light = mk(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
+        frame_light = average_samples(frame_light, p);
+        for (uint32_t f = 0; f < p.n_frames; f++) sum = (p.first_frame + f == 1u) ? frame_light : sum + frame_light;
+        if (VALIDATE) {
+            for (uint32_t f = 0; f < p.n_frames; f++) {
+                uint32_t fh = frame_hash_init(p.first_frame + f);
+                for (uint32_t k = 0; k < p.rays_per_pixel; k++) fh = (fh ^ kMissId) * kHashPrime;
+                hash += fh;
+            }
+            rng = (uint32_t)s.lin + (p.first_frame + p.n_frames - 1u) * 719393u;
+            for (uint32_t k = 0; k < p.rays_per_pixel; k++) rng += k;
+            seg.c[7] = 1u;   // one sky evaluation,
+            seg.c[9] = 1u;   // one path,
+            seg.c[10] = 1u;  // one segment per path
+            none.c[8] = p.n_frames;
+        }
+    }
+    finish_pixel<VALIDATE>(p, s.x, s.y, sky_pixel, sum, kMissId, hash, rng, none, seg, n_paths);
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant 2, second kernel: wave-cooperative path tracing of the compacted pixels.
+//
+// One wave (= one workgroup of 64 lanes) owns 64 list entries, taken with a stride of the wave count
+// so that every wave gets a sample of the whole image and all waves carry about the same load.  Lane
+// j evaluates entry j's primary hit once and parks what each of that pixel's paths starts from (hit
+// point, normal, mirror direction, material, seed base) in LDS.  The wave then walks its
+// 64 x n_frames work items (one frame of one pixel each, frame-major) together: lanes without work
+// take the next items in order (ballot + prefix count), trace them with the flattened segment loop,
+// and put the finished frame's radiance into ring[frame % kRing][pixel].  When all 64 items of the
+// oldest open frame are in, lane j adds that frame to pixel j's running sum, so each pixel's sum is
+// formed in frame order exactly as the shader forms it.  At most kRing frames are open at once.
+// Requires max_bounce >= 2 and rays_per_pixel >= 1.
+// --------------------------------------------------------------------------------------------
+constexpr int kPathsThreads = 64;
+constexpr uint32_t kRing = 8;
+
+enum PixField { F_POS = 0, F_NRM = 3, F_SPEC = 6, F_SMOOTH = 9, F_EMIT = 10, F_COLOR = 11, F_LIN = 14, F_PRIM = 15, F_COUNT = 16 };
+
+template <bool VALIDATE>
+__global__ __launch_bounds__(kPathsThreads) void k_paths(const RenderParams p)
+{
+    __shared__ float pix[F_COUNT][64];
+    __shared__ float ring[kRing][3][64];
+    __shared__ uint32_t done[kRing];
+    __shared__ uint32_t vhash[VALIDATE ? 64 : 1];
+    __shared__ uint32_t vrng[VALIDATE ? 64 : 1];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_hit = *p.hit_count;
+    const uint32_t n_waves = (n_hit + 63u) / 64u;
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_waves) return;
+    // entries gw, gw + n_waves, gw + 2 n_waves, ... ; they are valid for the first n_valid lanes
+    const uint32_t n_valid = (n_hit - gw + n_waves - 1u) / n_waves;
+    const bool valid = lane < n_valid;
+    const uint32_t pixel = valid ? p.hit_list[lane * n_waves + gw] : 0u;
+    const PixelSetup s = pixel_setup_xy(p, pixel % p.width, pixel / p.width, valid);
+    const Sky sky = make_sky(p);
+    const DeviceScene &sc = p.scene;
+    const uint32_t nS = p.sphere_number, nM = p.mesh_number;
+    Counters cn, seg;
+    zero(cn);
+    zero(seg);
+
+    // the pixel's primary segment, once
+    const Hit h0 = closest_hit<VALIDATE>(sc, nS, nM, s.origin, s.dir, seg);
+    {
+        V3 pos0 = s.origin, nrm0 = mk(0.0f, 1.0f, 0.0f);
+        float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float smooth0 = 0.0f;
+        if (valid && h0.prim != kMissId) {
+            resolve_hit(sc, nS, s.origin, s.dir, h0, pos0, nrm0);
+            m0 = sc.materials[2 * h0.mat + 0];
+            smooth0 = sc.materials[2 * h0.mat + 1].x;
+        }
+        const V3 spec0 = reflect(s.dir, nrm0);
+        pix[F_POS + 0][lane] = pos0.x;
+        pix[F_POS + 1][lane] = pos0.y;
+        pix[F_POS + 2][lane] = pos0.z;
+        pix[F_NRM + 0][lane] = nrm0.x;
+        pix[F_NRM + 1][lane] = nrm0.y;
+        pix[F_NRM + 2][lane] = nrm0.z;
+        pix[F_SPEC + 0][lane] = spec0.x;
+        pix[F_SPEC + 1][lane] = spec0.y;
+        pix[F_SPEC + 2][lane] = spec0.z;
+        pix[F_SMOOTH][lane] = smooth0;
+        pix[F_EMIT][lane] = m0.w;
+        pix[F_COLOR + 0][lane] = m0.x;
+        pix[F_COLOR + 1][lane] = m0.y;
+        pix[F_COLOR + 2][lane] = m0.z;
+        pix[F_LIN][lane] = s.lin;
+        pix[F_PRIM][lane] = __uint_as_float(h0.prim);
+    }
+    if (lane < kRing) done[lane] = 0u;
+    if (VALIDATE) {
+        vhash[lane] = 0u;
+        vrng[lane] = 0u;
+        seg.c[6] = 1u;                      // per path: the primary hit bounce,
+        seg.c[h0.prim < nS ? 2 : 5] = 1u;   // its winner kind,
+        seg.c[9] = 1u;                      // the path itself,
+        seg.c[10] = 1u;                     // and its first segment
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    V3 sum = load_sum(p, s.x, s.y, valid);   // lane j keeps pixel j's running sum
+
+    // wave-uniform progress: next item to hand out, oldest frame not yet added to the sums
+    const uint32_t total_items = p.n_frames * 64u;
+    uint32_t cursor = 0u, base = 0u;
+
+    // the item this lane is tracing
+    bool has_item = false;
+    uint32_t sl = 0u, fr = 0u, rng = 0u, k = 0u, i = 1u, fh = 0u;
+    V3 o = s.origin, d = s.dir;
+    V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
+
+    // first bounce of a path of pixel `sl` from its parked primary hit, Raytracing.comp:419-429
+    auto start_path = [&]() {
+        const V3 pos0 = mk(pix[F_POS + 0][sl], pix[F_POS + 1][sl], pix[F_POS + 2][sl]);
+        const V3 nrm0 = mk(pix[F_NRM + 0][sl], pix[F_NRM + 1][sl], pix[F_NRM + 2][sl]);
+        const V3 spec0 = mk(pix[F_SPEC + 0][sl], pix[F_SPEC + 1][sl], pix[F_SPEC + 2][sl]);
+        const float smooth0 = pix[F_SMOOTH][sl];
+        const float e0 = 1.0f * pix[F_EMIT][sl];
+        const V3 color0 = mk(pix[F_COLOR + 0][sl], pix[F_COLOR + 1][sl], pix[F_COLOR + 2][sl]);
+        const float rx = rng_next(rng) * 2.0f - 1.0f;
+        const float ry = rng_next(rng) * 2.0f - 1.0f;
+        const float rz = rng_next(rng) * 2.0f - 1.0f;
+        const V3 diffuse = normalize(nrm0 + mk(rx, ry, rz));
+        o = pos0;
+        d = gmix(diffuse, spec0, smooth0);
+        light = mk(0.0f, 0.0f, 0.0f) + mk(e0 * 1.0f, e0 * 1.0f, e0 * 1.0f);
+        thr = mk(1.0f, 1.0f, 1.0f) * color0;
+        i = 1u;
+        if (VALIDATE) fh = (fh ^ __float_as_uint(pix[F_PRIM][sl])) * kHashPrime;
+    };
+
+    while (base < p.n_frames) {
+        // 1. hand out work: lanes without an item take the next items in order
+        const unsigned long long need = __ballot(!has_item);
+        if (need != 0ull) {
+            const uint32_t window_end = (base + kRing) * 64u;
+            const uint32_t limit = window_end < total_items ? window_end : total_items;
+            const uint32_t avail = limit - cursor;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!has_item && rank < avail) {
+                const uint32_t item = cursor + rank;
+                fr = item >> 6;
+                sl = item & 63u;
+                if (sl < n_valid) {
+                    has_item = true;
+                    rng = (uint32_t)pix[F_LIN][sl] + (p.first_frame + fr) * 719393u;
+                    k = 0u;
+                    frame_light = mk(0.0f, 0.0f, 0.0f);
+                    if (VALIDATE) fh = frame_hash_init(p.first_frame + fr);
+                    start_path();
+                } else {
+                    __hip_atomic_fetch_add(&done[fr % kRing], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // no pixel behind this slot
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            cursor += wanted < avail ? wanted : avail;
+        }
+
+        // 2. one segment for every lane that holds an item
+        if (has_item) {
+            const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
+            if (VALIDATE) {
+                cn.c[10]++;
+                fh = (fh ^ h.prim) * kHashPrime;
+            }
+            bool path_done;
+            if (h.prim != kMissId) {
+                if (VALIDATE) {
+                    cn.c[6]++;
+                    if (h.prim < nS) cn.c[2]++;
+                    else cn.c[5]++;
+                }
+                bounce(sc, nS, h, o, d, light, thr, rng);
+                i++;
+                path_done = i >= p.max_bounce;
+            } else {
+                if (VALIDATE) cn.c[7]++;
+                light = light + env_light(sky, d) * thr;
+                path_done = true;
+            }
+            if (path_done) {
+                frame_light = frame_light + light;
+                k++;
+                if (k >= p.rays_per_pixel) {
+                    frame_light = average_samples(frame_light, p);
+                    const uint32_t slot = fr % kRing;
+                    ring[slot][0][sl] = frame_light.x;
+                    ring[slot][1][sl] = frame_light.y;
+                    ring[slot][2][sl] = frame_light.z;
+                    if (VALIDATE) {
+                        cn.c[8]++;
+                        __hip_atomic_fetch_add(&vhash[sl], fh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (fr == p.n_frames - 1u) vrng[sl] = rng;
+                    }
+                    // release: the ring stores above are in LDS before the count moves
+                    __hip_atomic_fetch_add(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    has_item = false;
+                } else {
+                    rng += k;
+                    start_path();
+                }
+            }
+        }
+
+        // 3. add every frame that is complete, oldest first, to the pixels' sums
+        __builtin_amdgcn_wave_barrier();
+        while (base < p.n_frames) {
+            const uint32_t slot = base % kRing;
+            const uint32_t arrived = __hip_atomic_load(&done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(arrived) != 64u) break;
+            const V3 fl = mk(ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane]);
+            sum = (p.first_frame + base == 1u) ? fl : sum + fl;
+            if (lane == 0u) __hip_atomic_store(&done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base++;
+        }
+    }
+
+    uint32_t hash = 0u, last_rng = 0u;
+    if (VALIDATE) {
+        hash = vhash[lane];
+        last_rng = vrng[lane];
+    }
+    finish_pixel<VALIDATE>(p, s.x, s.y, valid, sum, h0.prim, hash, last_rng, cn, seg, p.n_frames * p.rays_per_pixel);
 }
 
 // display image from an already summed accumulation image: rgba8 = unorm8(sum / divisor).  Also puts
@@ -291,13 +605,37 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest(int op, const float 
     out[i] = r;
 }
 
+// closest hit of n arbitrary rays against the uploaded scene (test hook)
+__global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, uint32_t n_spheres, uint32_t n_meshes,
+                                                                const float *__restrict__ origins, const float *__restrict__ dirs,
+                                                                size_t n, float *__restrict__ t_out, uint32_t *__restrict__ prim_out)
+{
+    const size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= n) return;
+    Counters cn;
+    const Hit h = closest_hit<false>(sc, n_spheres, n_meshes, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+                                     mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cn);
+    t_out[i] = h.t;
+    prim_out[i] = h.prim;
+}
+
 }  // namespace
+
+hipError_t rt_launch_selftest_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
+                                  const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((n + kBlockThreads - 1) / kBlockThreads), 1, 1);
+    hipLaunchKernelGGL(k_selftest_hit, grid, dim3(kBlockThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins, dirs, n,
+                       t_out, prim_out);
+    return hipGetLastError();
+}
 
 const char *rt_kernel_name(int variant)
 {
     switch (variant) {
     case 0: return "k_megakernel";
     case 1: return "k_regenerate";
+    case 2: return "k_classify+k_paths";
     default: return "unknown";
     }
 }
@@ -307,7 +645,9 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     if (p.width == 0 || p.height == 0 || p.n_frames == 0) return hipErrorInvalidValue;
     const dim3 grid((p.width + kTile - 1) / kTile, (p.height + kTile - 1) / kTile, 1);
     const dim3 block(kBlockThreads, 1, 1);
-    // the flattened loop assumes every path has at least one segment
+    // the flattened loops assume every path has at least one segment; the cached first bounce
+    // assumes at least one more after it
+    if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
     if (variant == 1 && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
     if (variant == 0) {
         if (validate) hipLaunchKernelGGL(k_megakernel<true>, grid, block, 0, stream, p);
@@ -315,6 +655,22 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     } else if (variant == 1) {
         if (validate) hipLaunchKernelGGL(k_regenerate<true>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(k_regenerate<false>, grid, block, 0, stream, p);
+    } else if (variant == 2) {
+        if (!p.hit_list || !p.hit_count) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        // one single-wave workgroup per 64 list entries; the list length is only known on the device,
+        // so the grid covers the worst case and surplus workgroups leave at once
+        const uint32_t n_pixels = p.width * p.height;
+        const dim3 grid_paths((n_pixels + 63u) / 64u, 1, 1);
+        const dim3 block_paths(kPathsThreads, 1, 1);
+        if (validate) {
+            hipLaunchKernelGGL(k_classify<true>, grid, block, 0, stream, p);
+            hipLaunchKernelGGL(k_paths<true>, grid_paths, block_paths, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(k_classify<false>, grid, block, 0, stream, p);
+            hipLaunchKernelGGL(k_paths<false>, grid_paths, block_paths, 0, stream, p);
+        }
     } else {
         return hipErrorInvalidValue;
     }

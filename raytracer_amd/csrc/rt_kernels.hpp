@@ -30,9 +30,13 @@ struct RenderParams {
     uint32_t *chain_hash;   // validation only
     uint32_t *rng_state;    // validation only
     unsigned long long *counters;  // validation only, 16 entries
+    uint32_t *hit_list;     // variant 2: pixels whose primary ray hits something, compacted
+    uint32_t *hit_count;    // variant 2: length of hit_list, zeroed before every launch
 };
 
 const char *rt_kernel_name(int variant);
 hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream);
 hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
+hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
+                                  const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream);
 hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);

@@ -25,7 +25,7 @@ static_assert(sizeof(rtmi_triangle) == 96, "triangle is 96 bytes");
 struct rtmi_ctx {
     int device = 0;
     uint32_t width = 0, height = 0;
-    int variant = RTMI_VARIANT_REGENERATE;
+    int variant = RTMI_VARIANT_COMPACT;
     bool validate = false;
     std::string err;
 
@@ -42,6 +42,7 @@ struct rtmi_ctx {
     float4 *accum = nullptr;
     uint32_t *out_rgba8 = nullptr;
     uint32_t *hit_ids = nullptr, *chain_hash = nullptr, *rng_state = nullptr;
+    uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list
     unsigned long long *counters = nullptr;
 
     // scene
@@ -130,6 +131,8 @@ int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out)
     c->accum = c->own_accum;
     if ((e = hipMalloc(&c->out_rgba8, np * 4)) != hipSuccess) return bail(e, "hipMalloc(rgba8)");
     if ((e = hipMalloc(&c->counters, RTMI_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMalloc(&c->hit_list, np * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(hit_list)");
+    if ((e = hipMalloc(&c->hit_count, 256)) != hipSuccess) return bail(e, "hipMalloc(hit_count)");
     // main.cpp:78-82: both images start zeroed
     if ((e = hipMemsetAsync(c->own_accum, 0, np * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(c->out_rgba8, 0, np * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -147,6 +150,8 @@ int rtmi_destroy(rtmi_ctx *c)
     (void)hipFree(c->own_accum);
     (void)hipFree(c->out_rgba8);
     (void)hipFree(c->hit_ids);
+    (void)hipFree(c->hit_list);
+    (void)hipFree(c->hit_count);
     (void)hipFree(c->chain_hash);
     (void)hipFree(c->rng_state);
     (void)hipFree(c->counters);
@@ -321,13 +326,13 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.accum = c->accum;
     p.out_rgba8 = c->out_rgba8;
     p.hit_ids = c->hit_ids;
+    p.hit_list = c->hit_list;
+    p.hit_count = c->hit_count;
     p.chain_hash = c->chain_hash;
     p.rng_state = c->rng_state;
     p.counters = c->counters;
 
     int variant = c->variant;
-    if (variant == RTMI_VARIANT_WAVEFRONT)
-        return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render: the wavefront variant is not built in this version");
     hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;
     if (c->ev_logging) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -358,7 +363,7 @@ int rtmi_render(rtmi_ctx *c, const rtmi_frame_data *fd)
 int rtmi_set_variant(rtmi_ctx *c, int variant)
 {
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
-    if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE)
+    if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE && variant != RTMI_VARIANT_COMPACT)
         return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_variant: variant %d not available", variant);
     c->variant = variant;
     return RTMI_OK;
@@ -541,6 +546,33 @@ int rtmi_selftest_math(rtmi_ctx *c, int op, const float *x, const float *y, floa
     (void)hipFree(dx);
     (void)hipFree(dy);
     (void)hipFree(dout);
+    return rc;
+}
+
+int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh_number, const float *origins,
+                              const float *directions, size_t n, float *t_out, uint32_t *prim_out)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!origins || !directions || !t_out || !prim_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_selftest_closest_hit: NULL argument");
+    if (!c->has_scene) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_selftest_closest_hit: no scene uploaded");
+    if (sphere_number > c->n_spheres || mesh_number > c->n_meshes)
+        return fail(c, RTMI_ERR_SCENE_MISMATCH, "rtmi_selftest_closest_hit: counts exceed the uploaded scene");
+    if (n == 0) return RTMI_OK;
+    if (int rc = use_device(c)) return rc;
+    float *dbuf = nullptr;
+    int rc = RTMI_OK;
+    // one allocation: origins | directions | t | prim
+    hipError_t e = hipMalloc(&dbuf, n * 8 * sizeof(float));
+    float *d_o = dbuf, *d_d = dbuf + 3 * n, *d_t = dbuf + 6 * n;
+    uint32_t *d_p = reinterpret_cast<uint32_t *>(dbuf + 7 * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rt_launch_selftest_hit(c->dscene, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_out, d_p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_closest_hit: %s", hipGetErrorString(e));
+    (void)hipFree(dbuf);
     return rc;
 }
 

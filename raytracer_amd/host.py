@@ -145,7 +145,7 @@ def make_frame_data(width, height, scene=None, pose=DEFAULT_POSE, rays_per_pixel
 class Renderer:
     """One context = one GPU, one image extent (rtmi_create ... rtmi_destroy)."""
 
-    def __init__(self, width, height, device=0, variant=abi.VARIANT_REGENERATE):
+    def __init__(self, width, height, device=0, variant=abi.VARIANT_COMPACT):
         self._lib = abi.load()
         self._ctx = C.c_void_p()
         self.width, self.height = int(width), int(height)
@@ -257,6 +257,17 @@ class Renderer:
         out = np.zeros(abi.N_COUNTERS, dtype=np.uint64)
         self._check(self._lib.rtmi_get_counters(self._ctx, out.ctypes.data, abi.N_COUNTERS))
         return dict(zip(abi.COUNTER_NAMES, (int(v) for v in out)))
+
+    def selftest_closest_hit(self, sphere_number, mesh_number, origins, directions):
+        """(t, prim_id) of each ray against the uploaded scene; rays are [n, 3] arrays."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        t = np.empty(len(o), dtype=np.float32)
+        prim = np.empty(len(o), dtype=np.uint32)
+        self._check(self._lib.rtmi_selftest_closest_hit(self._ctx, sphere_number, mesh_number, o.ctypes.data,
+                                                        d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
+        return t, prim
 
     def selftest_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -114,8 +114,24 @@ def lib():
                              C.c_int]
     L.orc_render_rows.restype = C.c_int
     L.orc_render_rows.argtypes = L.orc_render.argtypes + [C.c_uint32, C.c_uint32]
+    L.orc_closest_hit.restype = None
+    L.orc_closest_hit.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Sphere), C.POINTER(Triangle), C.POINTER(Mesh),
+                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _lib = L
     return L
+
+
+def closest_hit(scene, origins, directions, sphere_count=None, mesh_count=None):
+    """(t, prim_id) per ray, rays as [n, 3] float32 arrays."""
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    t = np.empty(len(o), dtype=np.float32)
+    prim = np.empty(len(o), dtype=np.uint32)
+    lib().orc_closest_hit(scene.n_spheres if sphere_count is None else sphere_count,
+                          scene.n_meshes.value if mesh_count is None else mesh_count,
+                          scene.spheres, scene.tris, scene.meshes, o.ctypes.data, d.ctypes.data, len(o),
+                          t.ctypes.data, prim.ctypes.data)
+    return t, prim
 
 
 def fl3(*v):

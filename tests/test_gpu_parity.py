@@ -11,7 +11,7 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1]
+VARIANTS = [0, 1, 2]
 
 
 def gpu_render(rtmi, case, variant, validate=True, per_frame=False):
@@ -278,10 +278,11 @@ def test_full_size_rows_against_oracle(rtmi, oracle, scene):
     """At the benchmark resolution the oracle checks whole rows (a pixel depends on no other pixel,
     so rows of a full render can be checked on their own): bottom, horizon, middle and top rows."""
     case = dict(FULL, scene=scene, pose=cases.BENCH_POSE, n=6)
-    got = gpu_render(rtmi, case, 1)
-    again = gpu_render(rtmi, case, 0)
-    assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
-    assert np.array_equal(got["chain_hash"], again["chain_hash"])
+    got = gpu_render(rtmi, case, 2)
+    for other in (0, 1):
+        again = gpu_render(rtmi, case, other)
+        assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
+        assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
     osc = cases.oracle_scene(case)
     ofd = cases.oracle_frame_data(case, osc)
     for y0 in (0, 300, 539, 1079):
@@ -304,7 +305,7 @@ def test_full_size_split_invariance_256_frames(rtmi):
     case = dict(FULL, scene="spheres", pose=cases.BENCH_POSE)
     sc = cases.product_scene(case)
     fd = cases.product_frame_data(case, sc)
-    with rtmi.Renderer(1920, 1080, variant=1) as r:
+    with rtmi.Renderer(1920, 1080, variant=2) as r:
         r.upload_scene(sc)
         r.render_frames(fd, 1, 256)
         one = r.read_accum()
@@ -313,11 +314,105 @@ def test_full_size_split_invariance_256_frames(rtmi):
             r.render_frames(fd, 1 + 64 * k, 64)
         four = r.read_accum()
         out_four = r.read_output_rgba8()
-        r.set_variant(0)
-        r.render_frames(fd, 1, 256)
-        nested = r.read_accum()
-    assert np.array_equal(one.view(np.uint32), four.view(np.uint32)) and np.array_equal(out_one, out_four)
-    assert np.array_equal(one.view(np.uint32), nested.view(np.uint32))
+        assert np.array_equal(one.view(np.uint32), four.view(np.uint32)) and np.array_equal(out_one, out_four)
+        for other in (0, 1):
+            r.set_variant(other)
+            r.render_frames(fd, 1, 256)
+            same = np.array_equal(one.view(np.uint32), r.read_accum().view(np.uint32))
+            assert same, "variant %d differs from variant 2" % other
     assert np.isfinite(one).all() and (one[..., 3] == 1.0).all()
     mean = one[..., :3] / 256.0
     assert 0.2 < mean.mean() < 2.0
+
+
+# ---- ClosestHit on hand-made rays -----------------------------------------------------------------
+
+def _oracle_sphere_scene(oracle, table):
+    return oracle.Scene([oracle.make_sphere(c, r, oracle.material((1, 1, 1), 0.0, 0.0)) for c, r in table])
+
+
+def _product_sphere_scene(rtmi, table):
+    return rtmi.Scene([rtmi.sphere(c, r, rtmi.material((1, 1, 1))) for c, r in table])
+
+
+def _check_rays(rtmi, oracle, sc, osc, o, d, ns, nm):
+    with rtmi.Renderer(8, 8) as r:
+        r.upload_scene(sc)
+        t, prim = r.selftest_closest_hit(ns, nm, o, d)
+    wt, wprim = oracle.closest_hit(osc, o, d, ns, nm)
+    same_t = cases.bits_equal(t, wt)
+    same_p = np.array_equal(prim, wprim)
+    assert same_p, "prim ids differ for %d rays" % int((prim != wprim).sum())
+    assert same_t, "t differs for %d rays" % int((t.view(np.uint32) != wt.view(np.uint32)).sum())
+    return t, prim
+
+
+def test_closest_hit_analytic(rtmi, oracle):
+    table = [((0.0, 0.0, 0.0), 1.0)]
+    sc, osc = _product_sphere_scene(rtmi, table), _oracle_sphere_scene(oracle, table)
+    o = np.array([[0, 0, -3], [0, 0, -3], [0, 0, 0], [0, 0, -3], [0, 1.5, -3]], dtype=np.float32)
+    d = np.array([[0, 0, 1], [0, 0, 0.5], [0, 0, 1], [0, 0, -1], [0, 0, 1]], dtype=np.float32)
+    t, prim = _check_rays(rtmi, oracle, sc, osc, o, d, 1, 0)
+    assert list(t[:2]) == [2.0, 4.0] and list(prim) == [0, 0, rtmi.abi.MISS_ID, rtmi.abi.MISS_ID, rtmi.abi.MISS_ID]
+    assert t[2] == np.float32(3.402823466e+38)
+    # reference scene: straight down onto the plane, onto the cube top, up from below (back faces culled)
+    sc, osc = rtmi.reference_scene(), oracle.reference_scene()
+    o = np.array([[1.5, 3, 1.5], [-1, 3, 0], [1.5, -3, 1.5], [-1, 1, 0]], dtype=np.float32)
+    d = np.array([[0, -1, 0], [0, -1, 0], [0, 1, 0], [0, 1, 0]], dtype=np.float32)
+    t, prim = _check_rays(rtmi, oracle, sc, osc, o, d, 1, 2)
+    assert t[0] == 3.0 and prim[0] in (1, 2) and t[1] == 1.5 and prim[1] >= 3
+    assert prim[2] == rtmi.abi.MISS_ID and prim[3] == rtmi.abi.MISS_ID   # from inside the cube every face is a back face
+
+
+def test_closest_hit_random_rays(rtmi, oracle):
+    rs = np.random.RandomState(5)
+    n = 20000
+    o = rs.uniform(-6, 6, size=(n, 3)).astype(np.float32)
+    d = (rs.normal(size=(n, 3)) * rs.uniform(0.2, 3.0, size=(n, 1))).astype(np.float32)
+    d[::7] = (np.array([0.0, 0.6, 0.0]) - o[::7]).astype(np.float32)          # aimed at the scene centre
+    d[::11, 1] = 0.0                                                           # parallel to the ground slab
+    case = dict(scene="spheres")
+    _check_rays(rtmi, oracle, cases.product_scene(case), cases.oracle_scene(case), o, d, 11, 0)
+    _check_rays(rtmi, oracle, rtmi.reference_scene(), oracle.reference_scene(), o, d, 1, 2)
+    _check_rays(rtmi, oracle, rtmi.reference_scene(quad_rule=1), oracle.reference_scene(quad_rule=1), o, d, 0, 2)
+
+
+def test_closest_hit_near_ties_and_threshold(rtmi, oracle):
+    """Rays built to land where comparing numerators and comparing rounded quotients could differ:
+    nearly coincident spheres (both index orders), exactly coincident spheres (lowest index wins),
+    roots at the 0.0001 threshold, and directions far outside the normal range."""
+    eps = np.float32(2.0 ** -20)
+    table = [((0.0, 0.0, 0.0), 1.0), ((0.0, 0.0, float(eps)), 1.0), ((0.0, 0.0, 0.0), 1.0),
+             ((0.0, 0.0, -float(eps)), float(np.float32(1.0) + eps)), ((3.0, 0.0, 0.0), 2.0 ** -10)]
+    sc, osc = _product_sphere_scene(rtmi, table), _oracle_sphere_scene(oracle, table)
+    rs = np.random.RandomState(8)
+    n = 4000
+    o = (rs.normal(size=(n, 3)) * 3.0).astype(np.float32)
+    d = (-o + rs.normal(size=(n, 3)) * 0.3).astype(np.float32)
+    d *= rs.choice([0.25, 0.5, 1.0, 2.0, 3.0], size=(n, 1)).astype(np.float32)
+    for ns in (5, 4, 3, 2):
+        t, prim = _check_rays(rtmi, oracle, sc, osc, o, d, ns, 0)
+    # exactly coincident spheres 0 and 2: sphere 2 never wins
+    assert not (prim == 2).any()
+    # roots around the t > 0.0001 threshold on the small sphere (index 4): origins one float apart
+    r = np.float32(2.0 ** -10)
+    steps = np.arange(-3000, 3000, dtype=np.int64)
+    for scale in (1.0, 0.5, 3.0):
+        # t is a ray parameter: the surface is 0.0001 * |d| away when t = 0.0001
+        base = np.float32(r + np.float32(0.0001 * scale))
+        z = (base.view(np.uint32).astype(np.int64) + steps).astype(np.uint32).view(np.float32)
+        o2 = np.stack([np.full_like(z, 3.0), np.zeros_like(z), -z], axis=1)
+        d2 = np.tile(np.array([0.0, 0.0, scale], dtype=np.float32), (len(z), 1))
+        t, prim = _check_rays(rtmi, oracle, sc, osc, o2, d2, 5, 0)
+        hit = prim == 4
+        assert hit.any() and (~hit).any()          # the scan straddles the threshold
+    # directions with denominators outside 2^-40 .. 2^40, zero, infinite and NaN directions
+    o3 = np.tile(np.array([[0.0, 0.0, -3.0]], dtype=np.float32), (8, 1))
+    d3 = np.array([[0, 0, 1e-25], [0, 0, 1e25], [0, 0, 0], [0, 0, np.inf], [np.nan, 0, 1], [0, 0, 1e-12], [0, 0, 3e19],
+                   [1e-30, 1e-30, 1e-22]], dtype=np.float32)
+    _check_rays(rtmi, oracle, sc, osc, o3, d3, 5, 0)
+    _check_rays(rtmi, oracle, rtmi.reference_scene(), oracle.reference_scene(), o3, d3, 1, 2)
+    # origins exactly on surfaces (what a bounce produces)
+    o4 = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0], [3, 0, -(2.0 ** -10)]], dtype=np.float32)
+    d4 = np.array([[0, 0, 1], [0, -1, 0.1], [-1, 0.2, 0], [0, 0, 1]], dtype=np.float32)
+    _check_rays(rtmi, oracle, sc, osc, o4, d4, 5, 0)
