@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_spheres", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1)")
-    ap.add_argument("--variant", type=int, default=1, help="0 nested megakernel, 1 regenerating megakernel")
+    ap.add_argument("--variant", type=int, default=2,
+                    help="0 nested megakernel, 1 regenerating megakernel, 2 classify + wave-cooperative paths (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -164,14 +165,15 @@ def main():
         "config": {
             "workload": "%s: %s scene, %dx%d, %d frames x 1 spp per GPU per step, max depth %d, bench pose" % (
                 args.workload, scene_name, width, height, frames, max_bounce),
-            "variant": ["megakernel", "regenerate"][args.variant],
+            "variant": ["megakernel", "regenerate", "compact"][args.variant],
             "frames_per_gpu": frames, "total_frames": total_frames,
             "parallelism": "frame-range split x%d + RCCL all-reduce(sum) of float4 accumulation" % world if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "fp32_valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": ["k_megakernel", "k_regenerate"][args.variant], "kernel_ms": kernel_ms, "launches_timed": launches,
+            "kernel": ["k_megakernel", "k_regenerate", "k_classify+k_paths (k_paths dominates)"][args.variant],
+            "kernel_ms": kernel_ms, "launches_timed": launches,
             "algorithmic_flops_per_launch": flops_per_launch,
             "algorithmic_hbm_bytes_per_launch": algorithmic_bytes,
             "hbm_gbs_algorithmic": algorithmic_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,

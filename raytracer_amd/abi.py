@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librtmi.so")
+# RTMI_LIBRARY selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RTMI_LIBRARY") or os.path.join(PKG_DIR, "librtmi.so")
 
 N_COUNTERS = 16
 COUNTER_NAMES = [

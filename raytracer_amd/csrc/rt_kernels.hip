@@ -372,7 +372,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
 // Requires max_bounce >= 2 and rays_per_pixel >= 1.
 // --------------------------------------------------------------------------------------------
 constexpr int kPathsThreads = 64;
-constexpr uint32_t kRing = 8;
+#ifndef RT_RING_FRAMES
+#define RT_RING_FRAMES 8
+#endif
+constexpr uint32_t kRing = RT_RING_FRAMES;
 
 enum PixField { F_POS = 0, F_NRM = 3, F_SPEC = 6, F_SMOOTH = 9, F_EMIT = 10, F_COLOR = 11, F_LIN = 14, F_PRIM = 15, F_COUNT = 16 };
 
