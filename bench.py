@@ -95,10 +95,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the library has no CPU fallback")
+    # Rehearsal aid for a one-GPU box: RTMI_BENCH_REHEARSE=1 puts every rank on GPU 0 and swaps RCCL
+    # for gloo (RCCL refuses two ranks on one device).  Never set by the driver; numbers are meaningless.
+    rehearse = os.environ.get("RTMI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     scene_name, width, height, max_bounce = WORKLOADS[args.workload]
     frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64}.get(args.workload, 256)

@@ -220,17 +220,19 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
         float best_n = __uint_as_float(0x7F800000u);
         uint32_t best_i = kMissId;
         bool ambiguous = !(a2 > 9.094947e-13f && a2 < 1.0995116e12f);  // 2^-40 .. 2^40
-        for (uint32_t i = 0; i < n_spheres; i++) {
-            const float4 g = ld_uniform(sc.sphere_geom, i);
+        // b and the discriminant of sphere g (Raytracing.comp:137-143)
+        auto quadratic = [&](const float4 g, float &b, float &disc) {
             V3 oc = o - mk(g.x, g.y, g.z);
-            float b = 2.0f * dot(oc, d);
+            b = 2.0f * dot(oc, d);
             float c = dot(oc, oc) - g.w;
-            float disc = b * b - a4 * c;
+            disc = b * b - a4 * c;
             if (COUNT) {
                 cn.c[0]++;
                 if (disc >= 0.0f) cn.c[1]++;
             }
-            // b >= 0 makes the numerator -b - sqrt(disc) <= 0, which can never pass t > 0.0001
+        };
+        // b >= 0 makes the numerator -b - sqrt(disc) <= 0, which can never pass t > 0.0001
+        auto candidate = [&](float b, float disc, uint32_t i) {
             if (disc >= 0.0f && b < 0.0f) {
                 const float n = -b - sqrtf(disc);
                 if (n > thr_lo && n < best_n) {
@@ -239,6 +241,22 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
                     best_i = i;
                 }
             }
+        };
+        // two records per trip: one scalar fetch and one wait for both, two independent quadratics
+        uint32_t i = 0;
+        for (; i + 1 < n_spheres; i += 2) {
+            const float4 g0 = ld_uniform(sc.sphere_geom, i);
+            const float4 g1 = ld_uniform(sc.sphere_geom, i + 1);
+            float b0, d0, b1, d1;
+            quadratic(g0, b0, d0);
+            quadratic(g1, b1, d1);
+            candidate(b0, d0, i);
+            candidate(b1, d1, i + 1);
+        }
+        if (i < n_spheres) {
+            float b0, d0;
+            quadratic(ld_uniform(sc.sphere_geom, i), b0, d0);
+            candidate(b0, d0, i);
         }
         if (best_i != kMissId) {
             best.t = best_n / a2;

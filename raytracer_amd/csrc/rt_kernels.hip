@@ -357,220 +357,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
     finish_pixel<VALIDATE>(p, s.x, s.y, sky_pixel, sum, kMissId, hash, rng, none, seg, n_paths);
 }
 
-// --------------------------------------------------------------------------------------------
-// Variant 2, second kernel: wave-cooperative path tracing of the compacted pixels.
-//
-// One wave (= one workgroup of 64 lanes) owns 64 list entries, taken with a stride of the wave count
-// so that every wave gets a sample of the whole image and all waves carry about the same load.  Lane
-// j evaluates entry j's primary hit once and parks what each of that pixel's paths starts from (hit
-// point, normal, mirror direction, material, seed base) in LDS.  The wave then walks its
-// 64 x n_frames work items (one frame of one pixel each, frame-major) together: lanes without work
-// take the next items in order (ballot + prefix count), trace them with the flattened segment loop,
-// and put the finished frame's radiance into ring[frame % kRing][pixel].  When all 64 items of the
-// oldest open frame are in, lane j adds that frame to pixel j's running sum, so each pixel's sum is
-// formed in frame order exactly as the shader forms it.  At most kRing frames are open at once.
-// Requires max_bounce >= 2 and rays_per_pixel >= 1.
-// --------------------------------------------------------------------------------------------
-constexpr int kPathsThreads = 64;
-#ifndef RT_RING_FRAMES
-#define RT_RING_FRAMES 8
-#endif
-constexpr uint32_t kRing = RT_RING_FRAMES;
-
-enum PixField { F_POS = 0, F_NRM = 3, F_SPEC = 6, F_SMOOTH = 9, F_EMIT = 10, F_COLOR = 11, F_LIN = 14, F_PRIM = 15, F_COUNT = 16 };
-
-template <bool VALIDATE>
-__global__ __launch_bounds__(kPathsThreads) void k_paths(const RenderParams p)
-{
-    __shared__ float pix[F_COUNT][64];
-    __shared__ float ring[kRing][3][64];
-    __shared__ uint32_t done[kRing];
-    __shared__ uint32_t vhash[VALIDATE ? 64 : 1];
-    __shared__ uint32_t vrng[VALIDATE ? 64 : 1];
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_hit = *p.hit_count;
-    const uint32_t n_waves = (n_hit + 63u) / 64u;
-    const uint32_t gw = blockIdx.x;
-    if (gw >= n_waves) return;
-    // entries gw, gw + n_waves, gw + 2 n_waves, ... ; they are valid for the first n_valid lanes
-    const uint32_t n_valid = (n_hit - gw + n_waves - 1u) / n_waves;
-    const bool valid = lane < n_valid;
-    const uint32_t pixel = valid ? p.hit_list[lane * n_waves + gw] : 0u;
-    const PixelSetup s = pixel_setup_xy(p, pixel % p.width, pixel / p.width, valid);
-    const Sky sky = make_sky(p);
-    const DeviceScene &sc = p.scene;
-    const uint32_t nS = p.sphere_number, nM = p.mesh_number;
-    Counters cn, seg;
-    zero(cn);
-    zero(seg);
-
-    // the pixel's primary segment, once
-    const Hit h0 = closest_hit<VALIDATE>(sc, nS, nM, s.origin, s.dir, seg);
-    {
-        V3 pos0 = s.origin, nrm0 = mk(0.0f, 1.0f, 0.0f);
-        float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float smooth0 = 0.0f;
-        if (valid && h0.prim != kMissId) {
-            resolve_hit(sc, nS, s.origin, s.dir, h0, pos0, nrm0);
-            m0 = sc.materials[2 * h0.mat + 0];
-            smooth0 = sc.materials[2 * h0.mat + 1].x;
-        }
-        const V3 spec0 = reflect(s.dir, nrm0);
-        pix[F_POS + 0][lane] = pos0.x;
-        pix[F_POS + 1][lane] = pos0.y;
-        pix[F_POS + 2][lane] = pos0.z;
-        pix[F_NRM + 0][lane] = nrm0.x;
-        pix[F_NRM + 1][lane] = nrm0.y;
-        pix[F_NRM + 2][lane] = nrm0.z;
-        pix[F_SPEC + 0][lane] = spec0.x;
-        pix[F_SPEC + 1][lane] = spec0.y;
-        pix[F_SPEC + 2][lane] = spec0.z;
-        pix[F_SMOOTH][lane] = smooth0;
-        pix[F_EMIT][lane] = m0.w;
-        pix[F_COLOR + 0][lane] = m0.x;
-        pix[F_COLOR + 1][lane] = m0.y;
-        pix[F_COLOR + 2][lane] = m0.z;
-        pix[F_LIN][lane] = s.lin;
-        pix[F_PRIM][lane] = __uint_as_float(h0.prim);
-    }
-    if (lane < kRing) done[lane] = 0u;
-    if (VALIDATE) {
-        vhash[lane] = 0u;
-        vrng[lane] = 0u;
-        seg.c[6] = 1u;                      // per path: the primary hit bounce,
-        seg.c[h0.prim < nS ? 2 : 5] = 1u;   // its winner kind,
-        seg.c[9] = 1u;                      // the path itself,
-        seg.c[10] = 1u;                     // and its first segment
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-
-    V3 sum = load_sum(p, s.x, s.y, valid);   // lane j keeps pixel j's running sum
-
-    // wave-uniform progress: next item to hand out, oldest frame not yet added to the sums
-    const uint32_t total_items = p.n_frames * 64u;
-    uint32_t cursor = 0u, base = 0u;
-
-    // the item this lane is tracing
-    bool has_item = false;
-    uint32_t sl = 0u, fr = 0u, rng = 0u, k = 0u, i = 1u, fh = 0u;
-    V3 o = s.origin, d = s.dir;
-    V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
-
-    // first bounce of a path of pixel `sl` from its parked primary hit, Raytracing.comp:419-429
-    auto start_path = [&]() {
-        const V3 pos0 = mk(pix[F_POS + 0][sl], pix[F_POS + 1][sl], pix[F_POS + 2][sl]);
-        const V3 nrm0 = mk(pix[F_NRM + 0][sl], pix[F_NRM + 1][sl], pix[F_NRM + 2][sl]);
-        const V3 spec0 = mk(pix[F_SPEC + 0][sl], pix[F_SPEC + 1][sl], pix[F_SPEC + 2][sl]);
-        const float smooth0 = pix[F_SMOOTH][sl];
-        const float e0 = 1.0f * pix[F_EMIT][sl];
-        const V3 color0 = mk(pix[F_COLOR + 0][sl], pix[F_COLOR + 1][sl], pix[F_COLOR + 2][sl]);
-        const float rx = rng_next(rng) * 2.0f - 1.0f;
-        const float ry = rng_next(rng) * 2.0f - 1.0f;
-        const float rz = rng_next(rng) * 2.0f - 1.0f;
-        const V3 diffuse = normalize(nrm0 + mk(rx, ry, rz));
-        o = pos0;
-        d = gmix(diffuse, spec0, smooth0);
-        light = mk(0.0f, 0.0f, 0.0f) + mk(e0 * 1.0f, e0 * 1.0f, e0 * 1.0f);
-        thr = mk(1.0f, 1.0f, 1.0f) * color0;
-        i = 1u;
-        if (VALIDATE) fh = (fh ^ __float_as_uint(pix[F_PRIM][sl])) * kHashPrime;
-    };
-
-    while (base < p.n_frames) {
-        // 1. hand out work: lanes without an item take the next items in order
-        const unsigned long long need = __ballot(!has_item);
-        if (need != 0ull) {
-            const uint32_t window_end = (base + kRing) * 64u;
-            const uint32_t limit = window_end < total_items ? window_end : total_items;
-            const uint32_t avail = limit - cursor;
-            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            if (!has_item && rank < avail) {
-                const uint32_t item = cursor + rank;
-                fr = item >> 6;
-                sl = item & 63u;
-                if (sl < n_valid) {
-                    has_item = true;
-                    rng = (uint32_t)pix[F_LIN][sl] + (p.first_frame + fr) * 719393u;
-                    k = 0u;
-                    frame_light = mk(0.0f, 0.0f, 0.0f);
-                    if (VALIDATE) fh = frame_hash_init(p.first_frame + fr);
-                    start_path();
-                } else {
-                    __hip_atomic_fetch_add(&done[fr % kRing], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // no pixel behind this slot
-                }
-            }
-            const uint32_t wanted = (uint32_t)__popcll(need);
-            cursor += wanted < avail ? wanted : avail;
-        }
-
-        // 2. one segment for every lane that holds an item
-        if (has_item) {
-            const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
-            if (VALIDATE) {
-                cn.c[10]++;
-                fh = (fh ^ h.prim) * kHashPrime;
-            }
-            bool path_done;
-            if (h.prim != kMissId) {
-                if (VALIDATE) {
-                    cn.c[6]++;
-                    if (h.prim < nS) cn.c[2]++;
-                    else cn.c[5]++;
-                }
-                bounce(sc, nS, h, o, d, light, thr, rng);
-                i++;
-                path_done = i >= p.max_bounce;
-            } else {
-                if (VALIDATE) cn.c[7]++;
-                light = light + env_light(sky, d) * thr;
-                path_done = true;
-            }
-            if (path_done) {
-                frame_light = frame_light + light;
-                k++;
-                if (k >= p.rays_per_pixel) {
-                    frame_light = average_samples(frame_light, p);
-                    const uint32_t slot = fr % kRing;
-                    ring[slot][0][sl] = frame_light.x;
-                    ring[slot][1][sl] = frame_light.y;
-                    ring[slot][2][sl] = frame_light.z;
-                    if (VALIDATE) {
-                        cn.c[8]++;
-                        __hip_atomic_fetch_add(&vhash[sl], fh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (fr == p.n_frames - 1u) vrng[sl] = rng;
-                    }
-                    // release: the ring stores above are in LDS before the count moves
-                    __hip_atomic_fetch_add(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    has_item = false;
-                } else {
-                    rng += k;
-                    start_path();
-                }
-            }
-        }
-
-        // 3. add every frame that is complete, oldest first, to the pixels' sums
-        __builtin_amdgcn_wave_barrier();
-        while (base < p.n_frames) {
-            const uint32_t slot = base % kRing;
-            const uint32_t arrived = __hip_atomic_load(&done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane(arrived) != 64u) break;
-            const V3 fl = mk(ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane]);
-            sum = (p.first_frame + base == 1u) ? fl : sum + fl;
-            if (lane == 0u) __hip_atomic_store(&done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            base++;
-        }
-    }
-
-    uint32_t hash = 0u, last_rng = 0u;
-    if (VALIDATE) {
-        hash = vhash[lane];
-        last_rng = vrng[lane];
-    }
-    finish_pixel<VALIDATE>(p, s.x, s.y, valid, sum, h0.prim, hash, last_rng, cn, seg, p.n_frames * p.rays_per_pixel);
-}
+// Variant 2, second kernel: wave-cooperative tracing of the compacted pixels.
+#include "rt_paths.inc"
 
 // display image from an already summed accumulation image: rgba8 = unorm8(sum / divisor).  Also puts
 // the alpha of the sum back to 1 (a sum of k partial images carries alpha k).
