@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1
 EXTRA=$2
 mkdir -p "$ROOT/scratch"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden \
     -I"$ROOT/include" -I"$ROOT/raytracer_amd/csrc" $EXTRA \
     -c "$ROOT/raytracer_amd/csrc/rt_kernels.hip" -o "$ROOT/scratch/rt_kernels_$NAME.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$ROOT/scratch/librtmi_$NAME.so" \
