@@ -306,26 +306,41 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
                 const uint32_t start = __float_as_uint(lo.w);
                 const uint32_t count = __float_as_uint(hi.w);
                 for (uint32_t j = start; j < start + count; j++) {
+                    // the whole 64-byte record in one scalar fetch
                     const float4 P = ld_uniform(sc.tri_isect, 4 * j + 0);
+                    const float4 AB = ld_uniform(sc.tri_isect, 4 * j + 1);
+                    const float4 AC = ld_uniform(sc.tri_isect, 4 * j + 2);
                     const float4 N = ld_uniform(sc.tri_isect, 4 * j + 3);
                     if (COUNT) cn.c[4]++;
-                    float det = -dot(d, mk(N.x, N.y, N.z));
+                    const float det = -dot(d, mk(N.x, N.y, N.z));
                     if (det >= 1e-6f) {
-                        const float4 AB = ld_uniform(sc.tri_isect, 4 * j + 1);
-                        const float4 AC = ld_uniform(sc.tri_isect, 4 * j + 2);
-                        V3 ao = o - mk(P.x, P.y, P.z);
-                        V3 dao = cross(ao, d);
-                        float inv = 1.0f / det;
-                        float t = dot(ao, mk(N.x, N.y, N.z)) * inv;
-                        float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv;
-                        float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv;
-                        float w = 1.0f - u - v;
-                        if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
-                            best.t = t;
-                            best.prim = n_spheres + j;
-                            best.mat = sc.n_spheres + m;  // material rows follow the uploaded sphere count
-                            best.u = u;
-                            best.v = v;
+                        // numerators of t, u, v (Raytracing.comp:291-299 before the multiply by 1/det)
+                        const V3 ao = o - mk(P.x, P.y, P.z);
+                        const V3 dao = cross(ao, d);
+                        const float tn = dot(ao, mk(N.x, N.y, N.z));
+                        const float un = dot(mk(AC.x, AC.y, AC.z), dao);
+                        const float vn = -dot(mk(AB.x, AB.y, AB.z), dao);
+                        // 1/det is positive and at least 2^-128, so a numerator below -2^-20 gives a
+                        // product below zero (no underflow to -0); u + v exceeds 1 by 2^-11 or more when
+                        // un + vn > det (1 + 2^-10); t is beyond the best when tn > best.t det (1 + 2^-10).
+                        // Each of these makes the shader's test fail, so the divide is only made for
+                        // lanes that none of them rules out.
+                        const float lim = det * 1.0009765625f;
+                        const bool ruled_out = (tn < -9.5367431640625e-7f) | (un < -9.5367431640625e-7f) |
+                                               (vn < -9.5367431640625e-7f) | (un + vn > lim) | (tn > best.t * lim);
+                        if (!ruled_out) {
+                            const float inv = 1.0f / det;
+                            const float t = tn * inv;
+                            const float u = un * inv;
+                            const float v = vn * inv;
+                            const float w = 1.0f - u - v;
+                            if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
+                                best.t = t;
+                                best.prim = n_spheres + j;
+                                best.mat = sc.n_spheres + m;  // material rows follow the uploaded sphere count
+                                best.u = u;
+                                best.v = v;
+                            }
                         }
                     }
                 }

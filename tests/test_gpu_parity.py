@@ -377,6 +377,35 @@ def test_closest_hit_random_rays(rtmi, oracle):
     _check_rays(rtmi, oracle, rtmi.reference_scene(quad_rule=1), oracle.reference_scene(quad_rule=1), o, d, 0, 2)
 
 
+def test_closest_hit_triangle_edges(rtmi, oracle):
+    """Rays aimed exactly at triangle vertices, edge points and shared diagonals of the reference
+    meshes, rays starting on the faces (t = 0 hits count), and grazing rays: the places where the
+    kernels' early-out on the numerators of t, u, v has to agree with the shader's own test."""
+    sc, osc = rtmi.reference_scene(), oracle.reference_scene()
+    tris = np.array([[list(t.p1)[:3], list(t.p2)[:3], list(t.p3)[:3]] for t in list(osc.tris)[:14]], dtype=np.float32)
+    rs = np.random.RandomState(21)
+    targets = [tris[:, 0], tris[:, 1], tris[:, 2]]
+    for _ in range(40):
+        w = rs.dirichlet([0.3, 0.3, 0.3], size=14).astype(np.float32)   # many near edges and corners
+        w[rs.rand(14) < 0.5, rs.randint(0, 3)] = 0.0                     # exactly on an edge
+        w /= w.sum(axis=1, keepdims=True)
+        targets.append((tris * w[:, :, None]).sum(axis=1))
+    targets = np.concatenate(targets).astype(np.float32)
+    origins = rs.uniform(-5, 5, size=targets.shape).astype(np.float32)
+    origins[:, 1] = np.abs(origins[:, 1]) + 0.5
+    dirs = (targets - origins) * rs.choice([0.25, 0.5, 1.0, 2.0], size=(len(targets), 1)).astype(np.float32)
+    _check_rays(rtmi, oracle, sc, osc, origins, dirs, 1, 2)
+    _check_rays(rtmi, oracle, sc, osc, origins, dirs, 0, 2)
+    # rays that start on a face (what a bounce produces) and leave in random directions, some into the surface
+    starts = np.repeat(targets[:200], 4, axis=0)
+    out = rs.normal(size=starts.shape).astype(np.float32)
+    _check_rays(rtmi, oracle, sc, osc, starts, out, 1, 2)
+    # grazing along the plane and along cube faces
+    graze_o = np.array([[-3, 0, 0.3], [-3, 1e-7, 0.3], [-3, 0.5, 0.2], [-3, 1.5, 0.2], [-1.5, 3, 0.1]], dtype=np.float32)
+    graze_d = np.array([[1, 0, 0], [1, -1e-8, 0], [1, 0, 0], [1, 0, 0], [0, -1, 0]], dtype=np.float32)
+    _check_rays(rtmi, oracle, sc, osc, graze_o, graze_d, 1, 2)
+
+
 def test_closest_hit_near_ties_and_threshold(rtmi, oracle):
     """Rays built to land where comparing numerators and comparing rounded quotients could differ:
     nearly coincident spheres (both index orders), exactly coincident spheres (lowest index wins),
