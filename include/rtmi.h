@@ -102,7 +102,22 @@ typedef enum rtmi_variant {
                                       others are stream-compacted (wave ballot + prefix count) and traced by dense waves */
 } rtmi_variant;
 
-/* Event counters (uint64 each), index = rtmi_counter.  Same events the CPU oracle counts. */
+/* How ClosestHit (RT.comp:338-388) finds its candidates.  The reference loops over every sphere and
+ * every triangle of every mesh whose box the ray meets; that is also what RTMI_ACCEL_NONE does.  With
+ * a bounding volume hierarchy (built on the host at upload: one over the spheres, one per mesh) only
+ * the primitives near the ray get the shader's tests.  The hit returned is the same: the tests are
+ * the shader's own, the box tests carry margins for their rounding, and ties keep the shader's loop
+ * order.  RTMI_ACCEL_AUTO builds hierarchies when the scene holds more than 256 primitives.  The
+ * reference has no counterpart (its scenes hold 5 spheres and 12 triangles, main.cpp:125-164). */
+typedef enum rtmi_accel {
+    RTMI_ACCEL_AUTO = 0,
+    RTMI_ACCEL_NONE = 1,
+    RTMI_ACCEL_BVH  = 2
+} rtmi_accel;
+
+/* Event counters (uint64 each), index = rtmi_counter.  Same events the CPU oracle counts.  With a
+ * hierarchy in use, the three test counters count the tests actually made (box tests include the
+ * hierarchy's node boxes), which are fewer than the oracle's exhaustive loops make. */
 typedef enum rtmi_counter {
     RTMI_N_SPHERE_TESTS = 0,
     RTMI_N_SPHERE_DISC_GE0,
@@ -151,6 +166,10 @@ RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
 
 RTMI_API int rtmi_set_variant(rtmi_ctx *ctx, int variant);
 RTMI_API int rtmi_get_variant(const rtmi_ctx *ctx);
+/* Mode for the NEXT rtmi_upload_scene (default RTMI_ACCEL_AUTO); rtmi_get_acceleration tells what
+ * the uploaded scene uses: RTMI_ACCEL_NONE or RTMI_ACCEL_BVH. */
+RTMI_API int rtmi_set_acceleration(rtmi_ctx *ctx, int mode);
+RTMI_API int rtmi_get_acceleration(const rtmi_ctx *ctx);
 
 /* Accumulation image (binding 5, rgba32f, running SUM not mean; RT.comp:471-479). */
 RTMI_API int rtmi_clear_accum(rtmi_ctx *ctx);
@@ -185,7 +204,7 @@ RTMI_API int rtmi_timing_read(rtmi_ctx *ctx, double *total_ms, uint32_t *launche
  * fill the event counters; results of the images are unaffected. */
 RTMI_API int rtmi_enable_validation(rtmi_ctx *ctx, int on);
 RTMI_API int rtmi_read_hit_ids(rtmi_ctx *ctx, uint32_t *ids, size_t bytes);      /* first segment of the last frame */
-RTMI_API int rtmi_read_chain_hash(rtmi_ctx *ctx, uint32_t *hash, size_t bytes);  /* hash of all segment ids of the last call */
+RTMI_API int rtmi_read_chain_hash(rtmi_ctx *ctx, uint32_t *hash, size_t bytes);  /* per pixel: sum over the call's frames of a hash of that frame's segment ids */
 RTMI_API int rtmi_read_rng_state(rtmi_ctx *ctx, uint32_t *state, size_t bytes);  /* RNG state after the last frame */
 RTMI_API int rtmi_get_counters(rtmi_ctx *ctx, uint64_t *counters, size_t n);
 RTMI_API int rtmi_reset_counters(rtmi_ctx *ctx);
@@ -215,6 +234,16 @@ RTMI_API int rtmi_load_model(const char *path,
                              rtmi_mesh *meshes, uint32_t *n_meshes, uint32_t mesh_capacity,
                              const rtmi_material *material, const float translate[3], const float scale[3],
                              int quad_rule);
+
+/* The hierarchy builder that rtmi_upload_scene uses, callable on its own (no device needed): boxes
+ * holds n records {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}.  Writes 64-byte inner nodes
+ * {left box lo, left ref} {left box hi, right ref} {right box lo, 0} {right box hi, 0} to nodes_out,
+ * the leaf order (leaf position -> box index) to order_out and the root reference to root_out, and
+ * returns the number of nodes.  A reference is an inner node index, or a leaf: bit 31 set, bits 28-30
+ * the count (1..4), bits 0-27 the first leaf position counted from leaf_base; 0xFFFFFFFF for n = 0.
+ * No counterpart in the reference. */
+RTMI_API int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nodes_out, size_t nodes_bytes,
+                            uint32_t *order_out, uint32_t *root_out);
 
 /* Constants of main.cpp:116-123, 151-153 (rays_per_pixel 4, max bounces 6, sky / sun / ground). */
 RTMI_API void rtmi_default_frame_data(rtmi_frame_data *fd);

@@ -20,6 +20,10 @@ VARIANT_MEGAKERNEL = 0
 VARIANT_REGENERATE = 1
 VARIANT_COMPACT = 2
 
+ACCEL_AUTO = 0
+ACCEL_NONE = 1
+ACCEL_BVH = 2
+
 OK = 0
 ERR_INVALID_ARGUMENT = -1
 ERR_NO_DEVICE = -2
@@ -99,6 +103,8 @@ PROTOTYPES = {
     "rtmi_render_frames": (C.c_int, [_ctx, C.POINTER(FrameData), C.c_uint32, C.c_uint32]),
     "rtmi_set_variant": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_variant": (C.c_int, [_ctx]),
+    "rtmi_set_acceleration": (C.c_int, [_ctx, C.c_int]),
+    "rtmi_get_acceleration": (C.c_int, [_ctx]),
     "rtmi_clear_accum": (C.c_int, [_ctx]),
     "rtmi_read_accum": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "rtmi_write_accum": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
@@ -123,6 +129,8 @@ PROTOTYPES = {
     "rtmi_load_model": (C.c_int, [C.c_char_p, C.POINTER(Triangle), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Mesh), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Material), _f, _f, C.c_int]),
+    "rtmi_bvh_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.POINTER(C.c_uint32)]),
     "rtmi_default_frame_data": (None, [C.POINTER(FrameData)]),
     "rtmi_camera_init": (None, [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
     "rtmi_camera_set_pose": (None, [C.POINTER(Camera), _f, C.c_float, C.c_float]),

@@ -1,0 +1,46 @@
+// rt_bvh.hpp — host-side bounding volume hierarchy builder for scenes too large for the
+// brute-force loops of Raytracing.comp:343-368.  The reference has no acceleration structure; the
+// hierarchy only decides WHICH primitives get the shader's exact tests, never how they are tested.
+// Its boxes are the primitives' own bounds; the traversal grows them, per ray, by a bound on the
+// rounding error of those tests, so the closest hit found is the one the brute-force loops find.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace rtmi {
+
+// One inner node holds the boxes of both children: a visit fetches 64 bytes and tests two boxes.
+// margin_floor is the smallest "radius" of the primitives below the child (sphere radius; 0 for
+// triangles): the traversal's error margin shrinks with it (see rt_bvh_device.hpp).
+struct BvhNode {
+    float l_lo[3]; uint32_t left;    // child reference
+    float l_hi[3]; uint32_t right;   // child reference
+    float r_lo[3]; float l_margin_floor;
+    float r_hi[3]; float r_margin_floor;
+};
+static_assert(sizeof(BvhNode) == 64, "node is 64 bytes");
+
+// Child reference: inner node index, or a leaf: kLeafFlag | count << 28 | first (range of the
+// leaf-ordered primitive arrays).  kEmptyRef marks "no primitives".
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
+constexpr uint32_t kLeafSize = 4;
+constexpr int kMaxDepth = 30;  // inner-node levels; the traversal stack holds 32 entries
+
+struct PrimBox {
+    float lo[3], hi[3];
+    float margin_floor = 0.0f;
+};
+
+// Builds a hierarchy over boxes[0..n) top-down: each range is split where a 16-bin sweep along the
+// widest axis of its centroids finds the smallest (surface area x count) sum, as long as both sides
+// can still be finished within kMaxDepth levels; otherwise (and when all centroids coincide) the
+// range is halved.  Leaves hold at most kLeafSize primitives.  Appends inner nodes to `nodes`,
+// returns the root reference, and fills order[k] = index of the primitive at leaf position k
+// (order is local to this call: 0..n-1).  Leaf references count from leaf_base, so that several
+// hierarchies can share one leaf-ordered primitive array (leaf_base + n must stay below 2^28).
+uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes, std::vector<uint32_t> &order,
+                  uint32_t leaf_base);
+
+}  // namespace rtmi

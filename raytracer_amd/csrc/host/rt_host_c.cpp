@@ -3,6 +3,7 @@
 #include <new>
 #include <vector>
 
+#include "rt_bvh.hpp"
 #include "rt_host.hpp"
 
 namespace {
@@ -130,6 +131,30 @@ void rtmi_frame_advance(rtmi_frame_data *fd, const rtmi_camera *cam, int reset_k
     if (!fd || !cam) return;
     rtmi::CameraFPS c = CameraFromC(cam);
     rtmi::FrameAdvance(*fd, c, reset_key != 0);
+}
+
+int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nodes_out, size_t nodes_bytes,
+                   uint32_t *order_out, uint32_t *root_out)
+{
+    if ((n && !boxes) || (n && !order_out) || !root_out) return RTMI_ERR_INVALID_ARGUMENT;
+    if (n >= (1u << 28) || (uint64_t)leaf_base + n >= (1u << 28)) return RTMI_ERR_UNSUPPORTED;
+    try {
+        std::vector<rtmi::PrimBox> pb(n);
+        for (uint32_t i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) {
+                pb[i].lo[a] = boxes[6 * (size_t)i + a];
+                pb[i].hi[a] = boxes[6 * (size_t)i + 3 + a];
+            }
+        std::vector<rtmi::BvhNode> nodes;
+        std::vector<uint32_t> order;
+        *root_out = rtmi::BuildBvh(pb, nodes, order, leaf_base);
+        if (nodes.size() * sizeof(rtmi::BvhNode) > nodes_bytes || (!nodes.empty() && !nodes_out)) return RTMI_ERR_OUT_OF_MEMORY;
+        if (!nodes.empty()) std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(rtmi::BvhNode));
+        if (n) std::memcpy(order_out, order.data(), (size_t)n * sizeof(uint32_t));
+        return (int)nodes.size();
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    }
 }
 
 int rtmi_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb)

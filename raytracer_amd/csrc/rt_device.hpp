@@ -163,6 +163,14 @@ struct DeviceScene {
     const float4 *mesh_box;     // [M][2]   {lo.xyz, bits(start)} {hi.xyz, bits(count)}
     const float4 *materials;    // [S + M][2] {r, g, b, light} {smoothness, 0, 0, 0}
     uint32_t n_spheres, n_triangles, n_meshes;
+    // bounding volume hierarchy (only for scenes too large for the uniform loops; null otherwise)
+    const float4 *bvh_nodes;        // [N][4]   {l.lo, bits(left)} {l.hi, bits(right)} {r.lo,-} {r.hi,-}
+    const float4 *bvh_sphere_geom;  // [S]      sphere_geom in leaf order
+    const uint32_t *bvh_sphere_id;  // [S]      sphere index of each leaf-order entry
+    const float4 *bvh_tri_isect;    // [L][4]   tri_isect in leaf order (L = sum of the meshes' counts)
+    const uint32_t *bvh_tri_id;     // [L]      triangle index of each leaf-order entry
+    const uint32_t *bvh_mesh_root;  // [M]      root reference of each mesh's hierarchy
+    uint32_t bvh_sphere_root;       // root reference of the sphere hierarchy
 };
 
 // Fetch of a record whose index is the same in every lane.  The scene arrays are never written by a

@@ -20,6 +20,7 @@
 #include "rt_kernels.hpp"
 
 #include "rt_device.hpp"
+#include "rt_bvh_device.hpp"
 
 #pragma clang fp contract(off)
 
@@ -111,6 +112,21 @@ __device__ __forceinline__ void zero(Counters &c)
     for (int i = 0; i < 11; i++) c.c[i] = 0u;
 }
 
+// Closest hit by the uniform loops or through the hierarchy; the choice is made per launch.
+template <bool COUNT, bool BVH>
+__device__ __forceinline__ Hit scene_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
+                                         Counters &cn, uint32_t *stack, uint32_t stride)
+{
+    if constexpr (BVH) return closest_hit_bvh<COUNT>(sc, n_spheres, n_meshes, o, d, cn, stack, stride);
+    else return closest_hit<COUNT>(sc, n_spheres, n_meshes, o, d, cn);
+}
+
+// per-lane traversal stacks of a workgroup of THREADS lanes: level l of lane t is word l * THREADS + t
+#define RT_BVH_STACK(THREADS)                                                     \
+    __shared__ uint32_t bvh_stack_mem[BVH ? kBvhStack * (THREADS) : 1];           \
+    uint32_t *const bvh_stack = &bvh_stack_mem[BVH ? threadIdx.x : 0u];           \
+    constexpr uint32_t bvh_stride = (THREADS)
+
 // Store one finished pixel (Raytracing.comp:479-480) and, in validating builds, its check values;
 // then fold the wave's event counters into the global totals.  Every lane of the wave must call it.
 // cn holds events counted one by one; per_path holds the events of one cached primary segment, which
@@ -156,9 +172,10 @@ __device__ __forceinline__ V3 load_sum(const RenderParams &p, uint32_t x, uint32
 // --------------------------------------------------------------------------------------------
 // Variant 0: loops nested exactly as the shader nests them.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE>
+template <bool VALIDATE, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams p)
 {
+    RT_BVH_STACK(kBlockThreads);
     const PixelSetup s = pixel_setup(p);
     const Sky sky = make_sky(p);
     const DeviceScene &sc = p.scene;
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
                 V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f);
                 if (VALIDATE) cn.c[9]++;
                 for (uint32_t i = 0; i < p.max_bounce; i++) {
-                    const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
+                    const Hit h = scene_hit<VALIDATE, BVH>(sc, nS, nM, o, d, cn, bvh_stack, bvh_stride);
                     if (VALIDATE) {
                         cn.c[10]++;
                         fh = (fh ^ h.prim) * kHashPrime;
@@ -216,9 +233,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
 // --------------------------------------------------------------------------------------------
 // Variant 1: one loop over segments; lanes regenerate their own next path.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE>
+template <bool VALIDATE, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams p)
 {
+    RT_BVH_STACK(kBlockThreads);
     const PixelSetup s = pixel_setup(p);
     const Sky sky = make_sky(p);
     const DeviceScene &sc = p.scene;
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
     if (VALIDATE && active) cn.c[9]++;
 
     while (active) {
-        const Hit h = closest_hit<VALIDATE>(sc, nS, nM, o, d, cn);
+        const Hit h = scene_hit<VALIDATE, BVH>(sc, nS, nM, o, d, cn, bvh_stack, bvh_stride);
         if (VALIDATE) {
             cn.c[10]++;
             fh = (fh ^ h.prim) * kHashPrime;
@@ -302,9 +320,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
 // appended to hit_list: the wave ballots its hit lanes, one lane reserves popcount slots with a single
 // atomic, and each hit lane takes the slot given by the count of hit lanes below it.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE>
+template <bool VALIDATE, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p)
 {
+    RT_BVH_STACK(kBlockThreads);
     const PixelSetup s = pixel_setup(p);
     const DeviceScene &sc = p.scene;
     const uint32_t nS = p.sphere_number, nM = p.mesh_number;
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
 
     bool hit = false;
     if (s.in_range) {
-        const Hit h0 = closest_hit<VALIDATE>(sc, nS, nM, s.origin, s.dir, seg);
+        const Hit h0 = scene_hit<VALIDATE, BVH>(sc, nS, nM, s.origin, s.dir, seg, bvh_stack, bvh_stride);
         hit = h0.prim != kMissId;
     }
 
@@ -397,27 +416,33 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest(int op, const float 
 }
 
 // closest hit of n arbitrary rays against the uploaded scene (test hook)
+template <bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, uint32_t n_spheres, uint32_t n_meshes,
                                                                 const float *__restrict__ origins, const float *__restrict__ dirs,
                                                                 size_t n, float *__restrict__ t_out, uint32_t *__restrict__ prim_out)
 {
+    RT_BVH_STACK(kBlockThreads);
     const size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x;
     if (i >= n) return;
     Counters cn;
-    const Hit h = closest_hit<false>(sc, n_spheres, n_meshes, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
-                                     mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cn);
+    const Hit h = scene_hit<false, BVH>(sc, n_spheres, n_meshes, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+                                        mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cn, bvh_stack, bvh_stride);
     t_out[i] = h.t;
     prim_out[i] = h.prim;
 }
 
 }  // namespace
 
-hipError_t rt_launch_selftest_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
+hipError_t rt_launch_selftest_hit(const DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream)
 {
     const dim3 grid((unsigned)((n + kBlockThreads - 1) / kBlockThreads), 1, 1);
-    hipLaunchKernelGGL(k_selftest_hit, grid, dim3(kBlockThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins, dirs, n,
-                       t_out, prim_out);
+    if (use_bvh)
+        hipLaunchKernelGGL(k_selftest_hit<true>, grid, dim3(kBlockThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins,
+                           dirs, n, t_out, prim_out);
+    else
+        hipLaunchKernelGGL(k_selftest_hit<false>, grid, dim3(kBlockThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins,
+                           dirs, n, t_out, prim_out);
     return hipGetLastError();
 }
 
@@ -440,12 +465,18 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     // assumes at least one more after it
     if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
     if (variant == 1 && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
+    const bool bvh = p.use_bvh != 0u;
+#define RT_LAUNCH(KERNEL, GRID, BLOCK)                                                                    \
+    do {                                                                                                  \
+        if (validate && bvh) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, stream, p);         \
+        else if (validate) hipLaunchKernelGGL((KERNEL<true, false>), GRID, BLOCK, 0, stream, p);          \
+        else if (bvh) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, stream, p);               \
+        else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, stream, p);                       \
+    } while (0)
     if (variant == 0) {
-        if (validate) hipLaunchKernelGGL(k_megakernel<true>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(k_megakernel<false>, grid, block, 0, stream, p);
+        RT_LAUNCH(k_megakernel, grid, block);
     } else if (variant == 1) {
-        if (validate) hipLaunchKernelGGL(k_regenerate<true>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(k_regenerate<false>, grid, block, 0, stream, p);
+        RT_LAUNCH(k_regenerate, grid, block);
     } else if (variant == 2) {
         if (!p.hit_list || !p.hit_count) return hipErrorInvalidValue;
         hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
@@ -455,13 +486,9 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
         const uint32_t n_pixels = p.width * p.height;
         const dim3 grid_paths((n_pixels + 63u) / 64u, 1, 1);
         const dim3 block_paths(kPathsThreads, 1, 1);
-        if (validate) {
-            hipLaunchKernelGGL(k_classify<true>, grid, block, 0, stream, p);
-            hipLaunchKernelGGL(k_paths<true>, grid_paths, block_paths, 0, stream, p);
-        } else {
-            hipLaunchKernelGGL(k_classify<false>, grid, block, 0, stream, p);
-            hipLaunchKernelGGL(k_paths<false>, grid_paths, block_paths, 0, stream, p);
-        }
+        RT_LAUNCH(k_classify, grid, block);
+        RT_LAUNCH(k_paths, grid_paths, block_paths);
+#undef RT_LAUNCH
     } else {
         return hipErrorInvalidValue;
     }

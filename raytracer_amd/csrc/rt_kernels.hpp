@@ -23,6 +23,7 @@ struct RenderParams {
     float rpp_recip;
 
     rtd::DeviceScene scene;
+    uint32_t use_bvh;       // closest hit through scene.bvh_* instead of the uniform loops
 
     float4 *accum;          // [height][width] running sum, w = 1
     uint32_t *out_rgba8;    // [height][width] packed r | g<<8 | b<<16 | a<<24
@@ -37,6 +38,6 @@ struct RenderParams {
 const char *rt_kernel_name(int variant);
 hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream);
 hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
-hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
+hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream);
 hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);

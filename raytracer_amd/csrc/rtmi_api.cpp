@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_bvh.hpp"
 #include "rt_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -51,6 +53,8 @@ struct rtmi_ctx {
     void *scene_blob = nullptr;
     size_t scene_blob_bytes = 0;
     rtd::DeviceScene dscene{};
+    int accel_mode = RTMI_ACCEL_AUTO;  // applied by the next rtmi_upload_scene
+    bool bvh_active = false;           // the uploaded scene carries hierarchies and the kernels use them
     std::vector<rtmi_mesh> host_meshes;  // kept for range checks against frame data
 };
 
@@ -89,6 +93,21 @@ int use_device(rtmi_ctx *ctx)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+// primitive count above which RTMI_ACCEL_AUTO builds hierarchies
+constexpr uint32_t kAutoBvhThreshold = 256;
+
+// largest float <= v and smallest float >= v
+inline float round_down(double v)
+{
+    float f = (float)v;
+    return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+inline float round_up(double v)
+{
+    float f = (float)v;
+    return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
 
 }  // namespace
 
@@ -190,7 +209,62 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     const size_t off_shd = align_up(off_tri + (size_t)nT * 64, 256);
     const size_t off_box = align_up(off_shd + (size_t)nT * 48, 256);
     const size_t off_mat = align_up(off_box + (size_t)nM * 32, 256);
-    const size_t total = align_up(off_mat + (size_t)(nS + nM) * 32, 256) + 256;
+    size_t total = align_up(off_mat + (size_t)(nS + nM) * 32, 256) + 256;
+
+    // Hierarchies: one over all spheres, one per mesh over that mesh's triangle range.  The boxes are
+    // the primitives' exact bounds (rounded outward); the margins that make skipping a box safe are
+    // applied by the traversal, relative to each ray.
+    const bool want_bvh = c->accel_mode == RTMI_ACCEL_BVH ||
+                          (c->accel_mode == RTMI_ACCEL_AUTO && (uint64_t)nS + nT > kAutoBvhThreshold);
+    std::vector<rtmi::BvhNode> nodes;
+    std::vector<uint32_t> sphere_order, tri_order;  // leaf position -> primitive index
+    std::vector<uint32_t> mesh_root(nM, rtmi::kEmptyRef);
+    uint32_t sphere_root = rtmi::kEmptyRef;
+    size_t off_nodes = 0, off_bsph = 0, off_bsid = 0, off_btri = 0, off_btid = 0, off_mroot = 0;
+    if (want_bvh) {
+        uint64_t leaf_total = 0;
+        for (uint32_t m = 0; m < nM; m++) leaf_total += (uint32_t)meshes[m].num_triangles;
+        if (nS >= (1u << 28) || leaf_total >= (1u << 28))
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than 2^28 primitives in a hierarchy");
+        try {
+            std::vector<rtmi::PrimBox> boxes(nS);
+            for (uint32_t i = 0; i < nS; i++) {
+                // the test uses the rounded square of the radius: 1e-6 relative covers that rounding
+                const double r = std::fabs((double)spheres[i].radius) * (1.0 + 1e-6);
+                for (int a = 0; a < 3; a++) {
+                    boxes[i].lo[a] = round_down((double)spheres[i].center[a] - r);
+                    boxes[i].hi[a] = round_up((double)spheres[i].center[a] + r);
+                }
+                boxes[i].margin_floor = (float)(std::fabs((double)spheres[i].radius) * 0.999999);
+            }
+            sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
+            tri_order.reserve(leaf_total);
+            std::vector<uint32_t> order;
+            for (uint32_t m = 0; m < nM; m++) {
+                const uint32_t start = (uint32_t)meshes[m].start_triangle, count = (uint32_t)meshes[m].num_triangles;
+                boxes.resize(count);
+                for (uint32_t k = 0; k < count; k++) {
+                    const rtmi_triangle &t = tris[start + k];
+                    for (int a = 0; a < 3; a++) {
+                        boxes[k].lo[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
+                        boxes[k].hi[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
+                    }
+                    boxes[k].margin_floor = 0.0f;
+                }
+                mesh_root[m] = rtmi::BuildBvh(boxes, nodes, order, (uint32_t)tri_order.size());
+                for (uint32_t k = 0; k < count; k++) tri_order.push_back(start + order[k]);
+            }
+        } catch (const std::bad_alloc &) {
+            return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation failed while building hierarchies");
+        }
+        off_nodes = align_up(total, 256);
+        off_bsph = align_up(off_nodes + nodes.size() * sizeof(rtmi::BvhNode), 256);
+        off_bsid = align_up(off_bsph + (size_t)nS * 16, 256);
+        off_btri = align_up(off_bsid + (size_t)nS * 4, 256);
+        off_btid = align_up(off_btri + tri_order.size() * 64, 256);
+        off_mroot = align_up(off_btid + tri_order.size() * 4, 256);
+        total = align_up(off_mroot + (size_t)nM * 4, 256) + 256;
+    }
     std::vector<unsigned char> blob(total, 0);
     float *sph = reinterpret_cast<float *>(blob.data() + off_sph);
     float *tri = reinterpret_cast<float *>(blob.data() + off_tri);
@@ -247,6 +321,23 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
         put_material(nS + m, ms.material);
     }
 
+    if (want_bvh) {
+        if (!nodes.empty()) memcpy(blob.data() + off_nodes, nodes.data(), nodes.size() * sizeof(rtmi::BvhNode));
+        float *bs = reinterpret_cast<float *>(blob.data() + off_bsph);
+        uint32_t *bi = reinterpret_cast<uint32_t *>(blob.data() + off_bsid);
+        for (uint32_t k = 0; k < nS; k++) {
+            memcpy(bs + 4 * (size_t)k, sph + 4 * (size_t)sphere_order[k], 16);
+            bi[k] = sphere_order[k];
+        }
+        float *bt = reinterpret_cast<float *>(blob.data() + off_btri);
+        uint32_t *bj = reinterpret_cast<uint32_t *>(blob.data() + off_btid);
+        for (size_t k = 0; k < tri_order.size(); k++) {
+            memcpy(bt + 16 * k, tri + 16 * (size_t)tri_order[k], 64);
+            bj[k] = tri_order[k];
+        }
+        if (nM) memcpy(blob.data() + off_mroot, mesh_root.data(), (size_t)nM * 4);
+    }
+
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->scene_blob_bytes < total) {
         (void)hipFree(c->scene_blob);
@@ -262,6 +353,14 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->dscene.tri_shade = reinterpret_cast<const float4 *>(base + off_shd);
     c->dscene.mesh_box = reinterpret_cast<const float4 *>(base + off_box);
     c->dscene.materials = reinterpret_cast<const float4 *>(base + off_mat);
+    c->dscene.bvh_nodes = want_bvh ? reinterpret_cast<const float4 *>(base + off_nodes) : nullptr;
+    c->dscene.bvh_sphere_geom = want_bvh ? reinterpret_cast<const float4 *>(base + off_bsph) : nullptr;
+    c->dscene.bvh_sphere_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_bsid) : nullptr;
+    c->dscene.bvh_tri_isect = want_bvh ? reinterpret_cast<const float4 *>(base + off_btri) : nullptr;
+    c->dscene.bvh_tri_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_btid) : nullptr;
+    c->dscene.bvh_mesh_root = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_mroot) : nullptr;
+    c->dscene.bvh_sphere_root = sphere_root;
+    c->bvh_active = want_bvh;
     c->dscene.n_spheres = nS;
     c->dscene.n_triangles = nT;
     c->dscene.n_meshes = nM;
@@ -323,6 +422,7 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.rpp_is_pow2 = is_pow2(fd->rays_per_pixel) ? 1u : 0u;
     p.rpp_recip = p.rpp_is_pow2 ? 1.0f / (float)fd->rays_per_pixel : 0.0f;
     p.scene = c->dscene;
+    p.use_bvh = c->bvh_active ? 1u : 0u;
     p.accum = c->accum;
     p.out_rgba8 = c->out_rgba8;
     p.hit_ids = c->hit_ids;
@@ -370,6 +470,17 @@ int rtmi_set_variant(rtmi_ctx *c, int variant)
 }
 
 int rtmi_get_variant(const rtmi_ctx *c) { return c ? c->variant : RTMI_ERR_INVALID_ARGUMENT; }
+
+int rtmi_set_acceleration(rtmi_ctx *c, int mode)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (mode != RTMI_ACCEL_AUTO && mode != RTMI_ACCEL_NONE && mode != RTMI_ACCEL_BVH)
+        return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_acceleration: mode %d not available", mode);
+    c->accel_mode = mode;
+    return RTMI_OK;
+}
+
+int rtmi_get_acceleration(const rtmi_ctx *c) { return c ? (c->bvh_active ? RTMI_ACCEL_BVH : RTMI_ACCEL_NONE) : RTMI_ERR_INVALID_ARGUMENT; }
 
 int rtmi_clear_accum(rtmi_ctx *c)
 {
@@ -567,7 +678,7 @@ int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh
     uint32_t *d_p = reinterpret_cast<uint32_t *>(dbuf + 7 * n);
     if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = rt_launch_selftest_hit(c->dscene, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream);
+    if (e == hipSuccess) e = rt_launch_selftest_hit(c->dscene, c->bvh_active, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(prim_out, d_p, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

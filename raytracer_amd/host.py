@@ -16,6 +16,17 @@ DEFAULT_POSE = ((0.0, 1.0, -1.0), -90.0, 0.0)   # CameraFPS.cpp:13, CameraFPS.h:
 BENCH_POSE = ((0.0, 1.5, -4.5), 90.0, -15.0)    # looks at the scene from in front and above
 
 
+# numpy views of the reference's records (RayTracingStructs.h:4-60): 32, 48, 96 and 80 bytes
+MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("light", "<f4"), ("smoothness", "<f4"), ("pad", "<f4", 3)])
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("material", MATERIAL_DTYPE)])
+TRIANGLE_DTYPE = np.dtype([("p1", "<f4", 4), ("p2", "<f4", 4), ("p3", "<f4", 4),
+                           ("n1", "<f4", 4), ("n2", "<f4", 4), ("n3", "<f4", 4)])
+MESH_DTYPE = np.dtype([("start_triangle", "<i4"), ("num_triangles", "<i4"), ("pad", "<f4", 2),
+                       ("bounding_point1", "<f4", 4), ("bounding_point2", "<f4", 4),
+                       ("material", MATERIAL_DTYPE)])
+assert (MATERIAL_DTYPE.itemsize, SPHERE_DTYPE.itemsize, TRIANGLE_DTYPE.itemsize, MESH_DTYPE.itemsize) == (32, 48, 96, 80)
+
+
 class RtmiError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("rtmi error %d: %s" % (code, message))
@@ -43,14 +54,32 @@ class Scene:
 
     def __init__(self, spheres=(), triangle_capacity=1 << 16, mesh_capacity=1 << 10):
         self.spheres = list(spheres)
+        self._sphere_arr = None  # set by from_records: a ready ctypes array instead of the list
         self._tris = (abi.Triangle * triangle_capacity)()
         self._meshes = (abi.Mesh * mesh_capacity)()
         self._n_tris = C.c_uint32(0)
         self._n_meshes = C.c_uint32(0)
 
+    @classmethod
+    def from_records(cls, spheres, triangles, meshes):
+        """Scene over numpy record arrays with the dtypes SPHERE_DTYPE / TRIANGLE_DTYPE / MESH_DTYPE
+        (the byte layouts of RayTracingStructs.h:4-60); for scenes too large for Python lists."""
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        triangles = np.ascontiguousarray(triangles, dtype=TRIANGLE_DTYPE)
+        meshes = np.ascontiguousarray(meshes, dtype=MESH_DTYPE)
+        sc = cls((), triangle_capacity=max(1, len(triangles)), mesh_capacity=max(1, len(meshes)))
+        sc._sphere_arr = (abi.Sphere * max(1, len(spheres)))()
+        sc._n_sphere_arr = len(spheres)
+        C.memmove(sc._sphere_arr, spheres.ctypes.data, spheres.nbytes)
+        C.memmove(sc._tris, triangles.ctypes.data, triangles.nbytes)
+        C.memmove(sc._meshes, meshes.ctypes.data, meshes.nbytes)
+        sc._n_tris.value = len(triangles)
+        sc._n_meshes.value = len(meshes)
+        return sc
+
     @property
     def n_spheres(self):
-        return len(self.spheres)
+        return self._n_sphere_arr if self._sphere_arr is not None else len(self.spheres)
 
     @property
     def n_triangles(self):
@@ -69,6 +98,8 @@ class Scene:
         return self._meshes
 
     def sphere_array(self):
+        if self._sphere_arr is not None:
+            return self._sphere_arr
         return (abi.Sphere * max(1, len(self.spheres)))(*self.spheres)
 
     def load_model(self, path, mat, translate=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), quad_rule=0):
@@ -181,6 +212,14 @@ class Renderer:
 
     def set_variant(self, variant):
         self._check(self._lib.rtmi_set_variant(self._ctx, variant))
+
+    def set_acceleration(self, mode):
+        """abi.ACCEL_AUTO / ACCEL_NONE / ACCEL_BVH for the next upload_scene."""
+        self._check(self._lib.rtmi_set_acceleration(self._ctx, mode))
+
+    def acceleration(self):
+        """What the uploaded scene uses: abi.ACCEL_NONE or abi.ACCEL_BVH."""
+        return self._check(self._lib.rtmi_get_acceleration(self._ctx))
 
     def upload_scene(self, scene):
         self._check(self._lib.rtmi_upload_scene(

@@ -159,6 +159,21 @@ class Scene:
         self.n_meshes = C.c_uint32(0)
         self.mesh_cap = mesh_cap
 
+    @classmethod
+    def from_product(cls, product_scene):
+        """Copy of a product-side scene: both sides hold the reference's record layouts
+        (RayTracingStructs.h:4-60), so the bytes carry over."""
+        ns, nt, nm = product_scene.n_spheres, product_scene.n_triangles, product_scene.n_meshes
+        sc = cls((), tri_cap=max(1, nt), mesh_cap=max(1, nm))
+        sc.spheres = (Sphere * max(1, ns))()
+        sc.n_spheres = ns
+        C.memmove(sc.spheres, product_scene.sphere_array(), ns * C.sizeof(Sphere))
+        C.memmove(sc.tris, product_scene.triangles, nt * C.sizeof(Triangle))
+        C.memmove(sc.meshes, product_scene.meshes, nm * C.sizeof(Mesh))
+        sc.n_tris.value = nt
+        sc.n_meshes.value = nm
+        return sc
+
     def load_model(self, path, mat, translate=(0, 0, 0), scale=(1, 1, 1), quad_rule=0):
         rc = lib().orc_load_model(path.encode(), self.tris, C.byref(self.n_tris), self.tri_cap,
                                   self.meshes, C.byref(self.n_meshes), self.mesh_cap,

@@ -1,0 +1,102 @@
+"""CPU tests of the hierarchy builder behind rtmi_upload_scene (rtmi_bvh_build needs no device)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+LEAF = 0x80000000
+EMPTY = 0xFFFFFFFF
+
+
+def build(rtmi, boxes, leaf_base=0):
+    lib = rtmi.abi.load()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    n = len(boxes)
+    nodes = np.zeros((max(1, n), 16), dtype=np.uint32)
+    order = np.zeros(max(1, n), dtype=np.uint32)
+    root = C.c_uint32()
+    rc = lib.rtmi_bvh_build(boxes.ctypes.data, n, leaf_base, nodes.ctypes.data, nodes.nbytes, order.ctypes.data,
+                            C.byref(root))
+    assert rc >= 0
+    return nodes[:rc], order[:n], root.value
+
+
+def walk(nodes, order, boxes, ref, leaf_base, seen, depth=1):
+    """Returns (lo, hi, depth) of the subtree; checks every stored child box against its contents."""
+    if ref & LEAF:
+        first, count = (ref & 0x0FFFFFFF) - leaf_base, (ref >> 28) & 7
+        assert 1 <= count <= 4
+        ids = order[first:first + count]
+        seen.extend(int(i) for i in ids)
+        b = boxes[ids]
+        return np.nanmin(b[:, :3], axis=0), np.nanmax(b[:, 3:], axis=0), depth
+    f = nodes[ref].view(np.float32)
+    out = []
+    for child, lo, hi in ((nodes[ref][3], f[0:3], f[4:7]), (nodes[ref][7], f[8:11], f[12:15])):
+        clo, chi, d = walk(nodes, order, boxes, int(child), leaf_base, seen, depth + 1)
+        assert (lo <= clo).all() and (hi >= chi).all()
+        assert (lo == clo).all() and (hi == chi).all()     # boxes are tight, margins belong to the traversal
+        out.append((clo, chi, d))
+    return np.minimum(out[0][0], out[1][0]), np.maximum(out[0][1], out[1][1]), max(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 9, 1000, 4097])
+def test_tree_covers_every_box_once(rtmi, n):
+    rs = np.random.RandomState(n)
+    c = rs.uniform(-10, 10, size=(n, 3))
+    r = rs.uniform(0.01, 0.5, size=(n, 3))
+    boxes = np.concatenate([c - r, c + r], axis=1).astype(np.float32)
+    leaf_base = 12345
+    nodes, order, root = build(rtmi, boxes, leaf_base)
+    assert sorted(order.tolist()) == list(range(n))
+    seen = []
+    _, _, depth = walk(nodes, order, boxes, root, leaf_base, seen)
+    assert sorted(seen) == list(range(n))
+    assert depth <= 31    # 30 levels of inner nodes and the leaves: what the traversal stack is sized for
+
+
+def test_empty_and_identical_boxes(rtmi):
+    nodes, order, root = build(rtmi, np.zeros((0, 6), dtype=np.float32))
+    assert len(nodes) == 0 and root == EMPTY
+    boxes = np.tile(np.array([[0, 0, 0, 1, 1, 1]], dtype=np.float32), (100, 1))
+    nodes, order, root = build(rtmi, boxes)
+    seen = []
+    walk(nodes, order, boxes, root, 0, seen)
+    assert sorted(seen) == list(range(100))
+    assert order.tolist() == list(range(100))      # equal Morton codes keep the input order
+
+
+def test_order_is_deterministic_and_spatial(rtmi):
+    rs = np.random.RandomState(3)
+    c = rs.uniform(0, 1, size=(5000, 3))
+    boxes = np.concatenate([c, c], axis=1).astype(np.float32)
+    a = build(rtmi, boxes)
+    b = build(rtmi, boxes)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and a[2] == b[2]
+    # neighbours in leaf order are close in space: mean step far below the mean distance of random pairs
+    step = np.linalg.norm(np.diff(c[a[1]], axis=0), axis=1).mean()
+    assert step < 0.15
+
+
+def test_depth_limit_on_adversarial_input(rtmi):
+    """Exponentially spaced points make every surface-area split peel off a few primitives; the builder
+    has to fall back to halving early enough to stay within the traversal stack."""
+    n = 20000
+    x = 2.0 ** np.linspace(-60, 60, n)
+    boxes = np.zeros((n, 6), dtype=np.float32)
+    boxes[:, 0] = boxes[:, 3] = x
+    nodes, order, root = build(rtmi, boxes)
+    seen = []
+    _, _, depth = walk(nodes, order, boxes, root, 0, seen)
+    assert sorted(seen) == list(range(n)) and depth <= 31
+
+
+def test_margin_floor_is_the_smallest_below(rtmi):
+    """Words 11 and 15 of a node: smallest margin floor below the left / right child (0 through this
+    entry point, which passes none)."""
+    rs = np.random.RandomState(9)
+    c = rs.uniform(-1, 1, size=(64, 3))
+    boxes = np.concatenate([c - 0.1, c + 0.1], axis=1).astype(np.float32)
+    nodes, _, _ = build(rtmi, boxes)
+    f = nodes.view(np.float32)
+    assert (f[:, 11] == 0).all() and (f[:, 15] == 0).all()
