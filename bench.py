@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2_spheres|c3_mesh|c4_mesh_4k]
+    python bench.py --gpus N --steps K --warmup W [--workload c2_spheres|c3_mesh|c4_mesh_4k|c5_stress]
 
 A step is one pass of the hot path over one batch: every GPU renders `--frames` frames (default
 256, 1 sample per pixel per frame, depth 8) of the workload's image in ONE kernel launch, inputs
@@ -35,23 +35,50 @@ WORKLOADS = {
     "c3_mesh": ("reference", 1920, 1080, 8),
     "c4_mesh_4k": ("reference", 3840, 2160, 8),
     "c1_plumbing": ("reference", 640, 360, 4),
+    # 10^6 spheres + 10^6 triangles (generated, seed 12345), traced through the hierarchy
+    "c5_stress": ("stress", 1920, 1080, 16),
 }
 
 
+def build_scene(R, scene_name):
+    """(product scene, camera pose) of a workload."""
+    if scene_name == "stress":
+        return R.scenes.stress_scene()
+    return (R.sphere_scene() if scene_name == "spheres" else R.reference_scene()), R.BENCH_POSE
+
+
 def cpu_baseline(workload, frames_hint, budget_s):
-    """Time the oracle on a bounded sample of the workload (same image, fewer frames)."""
+    """Time the oracle on a bounded sample of the workload (same image, fewer frames; for the stress
+    scene a coarser image of the same view)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     import oracle_lib as O
     scene_name, w, h, mb = WORKLOADS[workload]
-    case = dict(scene=scene_name, pose=cases.BENCH_POSE, size=(w, h), rpp=1, max_bounce=mb)
-    sc = cases.oracle_scene(case)
-    fd = cases.oracle_frame_data(case, sc)
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = os.cpu_count() or 1
     cores = max(1, min(affinity, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+    if scene_name == "stress":
+        import raytracer_amd as R
+        psc, pose = build_scene(R, scene_name)
+        sc = O.Scene.from_product(psc)
+        # the exhaustive loops cost about 0.1 s per pixel here, and the oracle's threads split image rows:
+        # the sample is the same view rendered at 64x36 (one path per 30x30 block of the benchmark's pixels)
+        sw, sh = 64, 36
+        fd = O.frame_data(sw, sh, pos=pose[0], yaw=pose[1], pitch=pose[2], rpp=1, max_bounce=mb, scene=sc)
+        t0 = time.perf_counter()
+        O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False)
+        dt = time.perf_counter() - t0
+        return {
+            "value": sw * sh / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": "%s scene and view at %dx%d instead of %dx%d, depth %d, frame 1, exhaustive loops over all "
+                      "primitives as the reference makes them (%.1f s of oracle time, OpenMP over rows)" % (
+                          workload, sw, sh, w, h, mb, dt),
+        }
+    case = dict(scene=scene_name, pose=cases.BENCH_POSE, size=(w, h), rpp=1, max_bounce=mb)
+    sc = cases.oracle_scene(case)
+    fd = cases.oracle_frame_data(case, sc)
     t0 = time.perf_counter()
     O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False)
     t1 = time.perf_counter() - t0
@@ -109,9 +136,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     scene_name, width, height, max_bounce = WORKLOADS[args.workload]
-    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64}.get(args.workload, 256)
-    scene = R.sphere_scene() if scene_name == "spheres" else R.reference_scene()
-    fd = R.make_frame_data(width, height, scene, R.BENCH_POSE, rays_per_pixel=1, max_bounce=max_bounce)
+    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 4}.get(args.workload, 256)
+    scene, pose = build_scene(R, scene_name)
+    fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
     total_frames = frames * world
 
     renderer = R.Renderer(width, height, device=local_rank, variant=args.variant)
@@ -159,20 +186,26 @@ def main():
     kernel_ms = kernel_ms_total / max(1, launches)
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     algorithmic_bytes = width * height * (16 + 4 + (0 if first == 1 else 16))   # accum write (+read) + rgba8
+    # HBM bytes per launch from the PMC passes kept under profiles/ (only valid for the configuration
+    # they were collected on)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            tj = json.load(f)
+        if tj.get("frames", 256) == frames and tj.get("variant", 2) == args.variant:
+            traffic = tj.get("hbm_bytes_per_launch")
 
     result = {
-        "metric": "Mpaths/s at 1080p depth-8" if height == 1080 else "Mpaths/s",
+        "metric": "Mpaths/s at 1080p depth-8" if (height, max_bounce) == (1080, 8) else "Mpaths/s",
         "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "%s: %s scene, %dx%d, %d frames x 1 spp per GPU per step, max depth %d, bench pose" % (
-                args.workload, scene_name, width, height, frames, max_bounce),
+            "workload": "%s: %s scene (%d spheres, %d triangles in %d meshes), %dx%d, %d frames x 1 spp per GPU per step, "
+                        "max depth %d, bench pose" % (args.workload, scene_name, scene.n_spheres, scene.n_triangles,
+                                                      scene.n_meshes, width, height, frames, max_bounce),
+            "closest_hit": "hierarchy" if renderer.acceleration() == R.abi.ACCEL_BVH else "exhaustive loops",
             "variant": ["megakernel", "regenerate", "compact"][args.variant],
             "frames_per_gpu": frames, "total_frames": total_frames,
             "parallelism": "frame-range split x%d + RCCL all-reduce(sum) of float4 accumulation" % world if world > 1 else "single GPU",
@@ -191,6 +224,21 @@ def main():
         "msegments_per_s": counters["n_segments"] / (kernel_ms * 1e-3) / 1e6,
         "counters_rank0_launch": counters,
     }
+    if renderer.acceleration() == R.abi.ACCEL_BVH:
+        # The hierarchy walk is a chain of dependent 64-byte gathers, bound by the memory system and not
+        # by arithmetic: price it by the bytes the walk has to fetch (two child boxes per node visit, a
+        # 20-byte record per sphere tested, a 68-byte record per triangle tested).
+        mesh_gates = counters["n_segments"] * fd.mesh_number
+        node_visits = (counters["n_box_tests"] - mesh_gates) // 2
+        gather_bytes = node_visits * 64 + counters["n_sphere_tests"] * 20 + counters["n_tri_tests"] * 68 + algorithmic_bytes
+        gbs = gather_bytes / (kernel_ms * 1e-3) / 1e9
+        result["roofline"].update({
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_gather_bytes_per_launch": gather_bytes, "node_visits_per_launch": node_visits,
+            "fp32_tflops_algorithmic": achieved_tflops,
+            "note": "hierarchy traversal: algorithmic bytes are the node and primitive records the walk fetches "
+                    "(served largely by L2 / Infinity Cache, so they bound cache traffic, not HBM traffic)",
+        })
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds)
     if rank == 0:

@@ -32,7 +32,7 @@ namespace rtd {
 
 constexpr uint32_t kBvhLeafFlag = 0x80000000u;
 constexpr uint32_t kBvhEmpty = 0xFFFFFFFFu;
-constexpr int kBvhStack = 32;  // a balanced tree over 2^28 leaf entries is at most 28 deep
+constexpr int kBvhStack = 24;  // one entry per level of inner nodes; the builder stops at 24 levels
 
 constexpr float kBvhSphereKappa = 1.4e-6f;             // > 19 * 2^-24
 constexpr float kBvhTriangleKappa = 5.9604644775e-8f;  // 2^-24: margin 2^-12 |ao|

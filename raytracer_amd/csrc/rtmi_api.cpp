@@ -14,10 +14,12 @@
 #include <vector>
 
 #include "rt_bvh.hpp"
+#include "rt_bvh_device.hpp"
 #include "rt_kernels.hpp"
 
 #pragma clang fp contract(off)
 
+static_assert(rtmi::kMaxDepth <= rtd::kBvhStack, "the traversal stack holds one entry per level the builder may create");
 static_assert(sizeof(rtmi_frame_data) == 260, "uniform block is 260 bytes");
 static_assert(sizeof(rtmi_material) == 32, "material is 32 bytes");
 static_assert(sizeof(rtmi_sphere) == 48, "sphere is 48 bytes");
@@ -224,8 +226,8 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     if (want_bvh) {
         uint64_t leaf_total = 0;
         for (uint32_t m = 0; m < nM; m++) leaf_total += (uint32_t)meshes[m].num_triangles;
-        if (nS >= (1u << 28) || leaf_total >= (1u << 28))
-            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than 2^28 primitives in a hierarchy");
+        if (nS > (1u << 26) || leaf_total > (1u << 26))
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than 2^26 primitives in the hierarchies");
         try {
             std::vector<rtmi::PrimBox> boxes(nS);
             for (uint32_t i = 0; i < nS; i++) {

@@ -52,7 +52,7 @@ def test_tree_covers_every_box_once(rtmi, n):
     seen = []
     _, _, depth = walk(nodes, order, boxes, root, leaf_base, seen)
     assert sorted(seen) == list(range(n))
-    assert depth <= 31    # 30 levels of inner nodes and the leaves: what the traversal stack is sized for
+    assert depth <= 25    # 24 levels of inner nodes and the leaves: what the traversal stack is sized for
 
 
 def test_empty_and_identical_boxes(rtmi):
@@ -88,7 +88,7 @@ def test_depth_limit_on_adversarial_input(rtmi):
     nodes, order, root = build(rtmi, boxes)
     seen = []
     _, _, depth = walk(nodes, order, boxes, root, 0, seen)
-    assert sorted(seen) == list(range(n)) and depth <= 31
+    assert sorted(seen) == list(range(n)) and depth <= 25
 
 
 def test_margin_floor_is_the_smallest_below(rtmi):
