@@ -181,6 +181,13 @@ RTMI_API int rtmi_read_output_rgba8(rtmi_ctx *ctx, uint8_t *rgba, size_t bytes);
  * the partial images of several GPUs, whose alphas add up). */
 RTMI_API int rtmi_resolve_output(rtmi_ctx *ctx, uint32_t divisor);
 
+/* Snapshot of the accumulation image plus the number of frames summed into it, and its reload into a
+ * context of the same extent (which also rebuilds the display image as sum / frames_done).  Going on
+ * with frame_index = frames_done + 1 gives the bits an uninterrupted run gives.  The reference keeps
+ * its accumulation image in device memory only (main.cpp:78-82) and cannot resume. */
+RTMI_API int rtmi_checkpoint_save(rtmi_ctx *ctx, const char *path, uint32_t frames_done);
+RTMI_API int rtmi_checkpoint_load(rtmi_ctx *ctx, const char *path, uint32_t *frames_done);
+
 /* Use a caller-owned device buffer of width*height float4 as the accumulation image (for example
  * memory that a collective library reduces in place).  NULL returns to the internal buffer.  The
  * shader has no counterpart; in Vulkan terms this is rebinding descriptor 5. */
@@ -234,6 +241,20 @@ RTMI_API int rtmi_load_model(const char *path,
                              rtmi_mesh *meshes, uint32_t *n_meshes, uint32_t mesh_capacity,
                              const rtmi_material *material, const float translate[3], const float scale[3],
                              int quad_rule);
+
+/* Text scene file holding the reference's records field by field (RayTracingStructs.h:24-60; the
+ * reference itself builds its scene from literals, main.cpp:125-185).  Lines: "rtmi-scene 1", then
+ * "sphere cx cy cz radius r g b light smoothness", "tri p1 p2 p3 n1 n2 n3" (xyz each) and
+ * "mesh start count lo hi r g b light smoothness"; '#' starts a comment line.  Floats are written
+ * with nine significant digits, so a saved scene loads back bit for bit.  rtmi_scene_load with all
+ * three arrays NULL only reports the counts; otherwise the arrays must be large enough
+ * (RTMI_ERR_OUT_OF_MEMORY if not; the counts are still reported). */
+RTMI_API int rtmi_scene_save(const char *path, const rtmi_sphere *spheres, uint32_t n_spheres,
+                             const rtmi_triangle *triangles, uint32_t n_triangles,
+                             const rtmi_mesh *meshes, uint32_t n_meshes);
+RTMI_API int rtmi_scene_load(const char *path, rtmi_sphere *spheres, uint32_t *n_spheres, uint32_t sphere_capacity,
+                             rtmi_triangle *triangles, uint32_t *n_triangles, uint32_t triangle_capacity,
+                             rtmi_mesh *meshes, uint32_t *n_meshes, uint32_t mesh_capacity);
 
 /* The hierarchy builder that rtmi_upload_scene uses, callable on its own (no device needed): boxes
  * holds n records {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}.  Writes 64-byte inner nodes

@@ -129,6 +129,13 @@ PROTOTYPES = {
     "rtmi_load_model": (C.c_int, [C.c_char_p, C.POINTER(Triangle), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Mesh), C.POINTER(C.c_uint32), C.c_uint32,
                                   C.POINTER(Material), _f, _f, C.c_int]),
+    "rtmi_checkpoint_save": (C.c_int, [_ctx, C.c_char_p, C.c_uint32]),
+    "rtmi_checkpoint_load": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "rtmi_scene_save": (C.c_int, [C.c_char_p, C.POINTER(Sphere), C.c_uint32, C.POINTER(Triangle), C.c_uint32,
+                                  C.POINTER(Mesh), C.c_uint32]),
+    "rtmi_scene_load": (C.c_int, [C.c_char_p, C.POINTER(Sphere), C.POINTER(C.c_uint32), C.c_uint32,
+                                  C.POINTER(Triangle), C.POINTER(C.c_uint32), C.c_uint32,
+                                  C.POINTER(Mesh), C.POINTER(C.c_uint32), C.c_uint32]),
     "rtmi_bvh_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.POINTER(C.c_uint32)]),
     "rtmi_default_frame_data": (None, [C.POINTER(FrameData)]),

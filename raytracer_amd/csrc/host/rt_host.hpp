@@ -82,6 +82,19 @@ struct Scene {
 };
 bool BuildReferenceScene(const std::string &meshDir, Scene &scene, QuadRule rule = QuadRule::ShorterDiagonal);
 
+// Text scene file: one record per line, floats with nine significant digits (exact for binary32).
+// LoadScene replaces `scene` only when the whole file parses and every mesh range is in bounds.
+bool SaveScene(const char *path, const Scene &scene);
+bool LoadScene(const char *path, Scene &scene);
+
+// Accumulation snapshot: the float4 running sum and the number of frames summed into it.
+struct Snapshot {
+    uint32_t width = 0, height = 0, frames = 0;
+    std::vector<float> accum;  // width * height * 4
+};
+bool SaveSnapshot(const char *path, uint32_t width, uint32_t height, uint32_t frames, const float *accumRgba);
+bool LoadSnapshot(const char *path, Snapshot &snap);
+
 bool WritePPM(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, bool srgb);
 bool WritePFM(const char *path, const float *accumRgba, uint32_t width, uint32_t height, uint32_t frames);
 

@@ -157,6 +157,46 @@ int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nod
     }
 }
 
+int rtmi_scene_save(const char *path, const rtmi_sphere *spheres, uint32_t n_spheres, const rtmi_triangle *triangles,
+                    uint32_t n_triangles, const rtmi_mesh *meshes, uint32_t n_meshes)
+{
+    if (!path || (n_spheres && !spheres) || (n_triangles && !triangles) || (n_meshes && !meshes)) return RTMI_ERR_INVALID_ARGUMENT;
+    try {
+        rtmi::Scene sc;
+        sc.spheres.assign(spheres, spheres + n_spheres);
+        sc.triangles.assign(triangles, triangles + n_triangles);
+        sc.meshes.assign(meshes, meshes + n_meshes);
+        return rtmi::SaveScene(path, sc) ? RTMI_OK : RTMI_ERR_IO;
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    }
+}
+
+int rtmi_scene_load(const char *path, rtmi_sphere *spheres, uint32_t *n_spheres, uint32_t sphere_capacity,
+                    rtmi_triangle *triangles, uint32_t *n_triangles, uint32_t triangle_capacity, rtmi_mesh *meshes,
+                    uint32_t *n_meshes, uint32_t mesh_capacity)
+{
+    if (!path || !n_spheres || !n_triangles || !n_meshes) return RTMI_ERR_INVALID_ARGUMENT;
+    try {
+        rtmi::Scene sc;
+        if (!rtmi::LoadScene(path, sc)) return RTMI_ERR_IO;
+        *n_spheres = (uint32_t)sc.spheres.size();
+        *n_triangles = (uint32_t)sc.triangles.size();
+        *n_meshes = (uint32_t)sc.meshes.size();
+        if (!spheres && !triangles && !meshes) return RTMI_OK;  // size query
+        if (sc.spheres.size() > sphere_capacity || sc.triangles.size() > triangle_capacity || sc.meshes.size() > mesh_capacity)
+            return RTMI_ERR_OUT_OF_MEMORY;
+        if ((!spheres && !sc.spheres.empty()) || (!triangles && !sc.triangles.empty()) || (!meshes && !sc.meshes.empty()))
+            return RTMI_ERR_INVALID_ARGUMENT;
+        if (!sc.spheres.empty()) std::memcpy(spheres, sc.spheres.data(), sc.spheres.size() * sizeof(rtmi_sphere));
+        if (!sc.triangles.empty()) std::memcpy(triangles, sc.triangles.data(), sc.triangles.size() * sizeof(rtmi_triangle));
+        if (!sc.meshes.empty()) std::memcpy(meshes, sc.meshes.data(), sc.meshes.size() * sizeof(rtmi_mesh));
+        return RTMI_OK;
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    }
+}
+
 int rtmi_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb)
 {
     if (!path || !rgba8 || !width || !height) return RTMI_ERR_INVALID_ARGUMENT;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "rt_bvh.hpp"
+#include "rt_host.hpp"
 #include "rt_bvh_device.hpp"
 #include "rt_kernels.hpp"
 
@@ -532,6 +533,55 @@ int rtmi_resolve_output(rtmi_ctx *c, uint32_t divisor)
     if (divisor == 0) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_resolve_output: divisor is 0");
     hipError_t e = rt_launch_resolve(c->accum, c->out_rgba8, (uint32_t)n_pixels(c), (float)divisor, c->stream);
     if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+// Snapshot of the accumulation image and the frame count it holds.  A context that loads it and goes
+// on with frame_index = frames_done + 1 produces the bits an uninterrupted run produces: a frame's
+// contribution depends only on pixel, frame index, scene and camera (Raytracing.comp:462), and the sum
+// is carried in this image alone (Raytracing.comp:471-477).
+int rtmi_checkpoint_save(rtmi_ctx *c, const char *path, uint32_t frames_done)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!path) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_checkpoint_save: path is NULL");
+    if (int rc = use_device(c)) return rc;
+    std::vector<float> host;
+    try {
+        host.resize(n_pixels(c) * 4);
+    } catch (const std::bad_alloc &) {
+        return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_checkpoint_save: host allocation failed");
+    }
+    HIP_TRY(c, hipMemcpyAsync(host.data(), c->accum, host.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!rtmi::SaveSnapshot(path, c->width, c->height, frames_done, host.data()))
+        return fail(c, RTMI_ERR_IO, "rtmi_checkpoint_save: cannot write %s", path);
+    return RTMI_OK;
+}
+
+int rtmi_checkpoint_load(rtmi_ctx *c, const char *path, uint32_t *frames_done)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!path || !frames_done) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_checkpoint_load: NULL argument");
+    rtmi::Snapshot snap;
+    try {
+        if (!rtmi::LoadSnapshot(path, snap)) return fail(c, RTMI_ERR_IO, "rtmi_checkpoint_load: %s is not a readable snapshot", path);
+    } catch (const std::bad_alloc &) {
+        return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_checkpoint_load: host allocation failed");
+    }
+    if (snap.width != c->width || snap.height != c->height)
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_checkpoint_load: snapshot is %ux%u, context is %ux%u", snap.width,
+                    snap.height, c->width, c->height);
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->accum, snap.accum.data(), snap.accum.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (snap.frames > 0) {
+        // the display image the interrupted run had after its last frame (Raytracing.comp:480)
+        hipError_t e = rt_launch_resolve(c->accum, c->out_rgba8, (uint32_t)n_pixels(c), (float)snap.frames, c->stream);
+        if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->out_rgba8, 0, n_pixels(c) * 4, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // snap.accum must outlive the copy
+    *frames_done = snap.frames;
     return RTMI_OK;
 }
 

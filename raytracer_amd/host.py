@@ -102,6 +102,33 @@ class Scene:
             return self._sphere_arr
         return (abi.Sphere * max(1, len(self.spheres)))(*self.spheres)
 
+    def save(self, path):
+        """Write the scene as a text scene file (rtmi_scene_save)."""
+        rc = abi.load().rtmi_scene_save(os.fspath(path).encode(), self.sphere_array(), self.n_spheres,
+                                        self._tris, self.n_triangles, self._meshes, self.n_meshes)
+        if rc < 0:
+            raise RtmiError(rc, "rtmi_scene_save(%s)" % path)
+
+    @classmethod
+    def load(cls, path):
+        """Read a text scene file (rtmi_scene_load)."""
+        lib = abi.load()
+        ns, nt, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        p = os.fspath(path).encode()
+        rc = lib.rtmi_scene_load(p, None, C.byref(ns), 0, None, C.byref(nt), 0, None, C.byref(nm), 0)
+        if rc < 0:
+            raise RtmiError(rc, "rtmi_scene_load(%s)" % path)
+        sc = cls((), triangle_capacity=max(1, nt.value), mesh_capacity=max(1, nm.value))
+        sc._sphere_arr = (abi.Sphere * max(1, ns.value))()
+        rc = lib.rtmi_scene_load(p, sc._sphere_arr, C.byref(ns), max(1, ns.value), sc._tris, C.byref(nt),
+                                 max(1, nt.value), sc._meshes, C.byref(nm), max(1, nm.value))
+        if rc < 0:
+            raise RtmiError(rc, "rtmi_scene_load(%s)" % path)
+        sc._n_sphere_arr = ns.value
+        sc._n_tris.value = nt.value
+        sc._n_meshes.value = nm.value
+        return sc
+
     def load_model(self, path, mat, translate=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), quad_rule=0):
         """LoadModel (ModelLoader.h:6-11).  Returns the number of triangles appended."""
         rc = abi.load().rtmi_load_model(
@@ -251,6 +278,15 @@ class Renderer:
 
     def clear_accum(self):
         self._check(self._lib.rtmi_clear_accum(self._ctx))
+
+    def save_checkpoint(self, path, frames_done):
+        self._check(self._lib.rtmi_checkpoint_save(self._ctx, os.fspath(path).encode(), frames_done))
+
+    def load_checkpoint(self, path):
+        """Returns the number of frames the snapshot holds; continue with frame_index = that + 1."""
+        n = C.c_uint32()
+        self._check(self._lib.rtmi_checkpoint_load(self._ctx, os.fspath(path).encode(), C.byref(n)))
+        return n.value
 
     def bind_accum(self, device_ptr):
         self._check(self._lib.rtmi_bind_accum(self._ctx, device_ptr))

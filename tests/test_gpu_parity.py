@@ -445,3 +445,57 @@ def test_closest_hit_near_ties_and_threshold(rtmi, oracle):
     o4 = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0], [3, 0, -(2.0 ** -10)]], dtype=np.float32)
     d4 = np.array([[0, 0, 1], [0, -1, 0.1], [-1, 0.2, 0], [0, 0, 1]], dtype=np.float32)
     _check_rays(rtmi, oracle, sc, osc, o4, d4, 5, 0)
+
+
+# ---- checkpoint / resume -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_checkpoint_resume_is_bit_exact(rtmi, tmp_path, variant):
+    """8 frames in one context == 3 frames, snapshot, new context, reload, 5 more frames."""
+    case = dict(cases.CASES["c3_mesh_bench_pose"])
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    path = tmp_path / "acc.snap"
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 8)
+        want = (r.read_accum(), r.read_output_rgba8())
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 3)
+        r.save_checkpoint(path, 3)
+        mid = (r.read_accum(), r.read_output_rgba8())
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        assert r.load_checkpoint(path) == 3
+        # the reloaded context shows what the interrupted one showed
+        assert cases.bits_equal(r.read_accum(), mid[0]) and np.array_equal(r.read_output_rgba8(), mid[1])
+        r.render_frames(fd, 4, 5)
+        got = (r.read_accum(), r.read_output_rgba8())
+    assert cases.bits_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_checkpoint_errors(rtmi, tmp_path):
+    path = tmp_path / "acc.snap"
+    with rtmi.Renderer(16, 8) as r:
+        r.save_checkpoint(path, 0)
+        assert r.load_checkpoint(path) == 0
+        assert not r.read_output_rgba8().any()
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.load_checkpoint(tmp_path / "missing.snap")
+        assert e.value.code == rtmi.abi.ERR_IO
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.save_checkpoint(tmp_path / "no_such_dir" / "x.snap", 1)
+        assert e.value.code == rtmi.abi.ERR_IO
+    with rtmi.Renderer(8, 16) as r:      # same pixel count, other extent
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.load_checkpoint(path)
+        assert e.value.code == rtmi.abi.ERR_INVALID_ARGUMENT
+    data = path.read_bytes()
+    for bad in (data[:-4], data + b"\0\0\0\0", b"RTMIACC2" + data[8:], data[:12]):
+        path.write_bytes(bad)
+        with rtmi.Renderer(16, 8) as r:
+            with pytest.raises(rtmi.RtmiError) as e:
+                r.load_checkpoint(path)
+            assert e.value.code == rtmi.abi.ERR_IO

@@ -178,3 +178,59 @@ def test_ppm_and_pfm_writers(rtmi, tmp_path):
     data = np.frombuffer(raw[len(head):], dtype="<f4").reshape(h, w, 3)
     assert np.array_equal(data, acc[..., :3] / 4.0)
     assert lib.rtmi_write_ppm(b"/nonexistent_dir/x.ppm", img.ctypes.data, w, h, 0) == rtmi.abi.ERR_IO
+
+
+def _records(sc, rtmi):
+    return (bytes(sc.sphere_array())[:48 * sc.n_spheres], bytes(sc.triangles)[:96 * sc.n_triangles],
+            bytes(sc.meshes)[:80 * sc.n_meshes])
+
+
+def test_scene_file_round_trip_is_bit_exact(rtmi, tmp_path):
+    """Every float of every record comes back with the same bits, including values that need all nine
+    digits, denormals, negative zero and infinities."""
+    sc, _ = rtmi.scenes.stress_scene(200, (6, 5), 3, seed=99, extent=3.0)
+    sph = np.frombuffer(sc.sphere_array(), dtype=rtmi.host.SPHERE_DTYPE, count=sc.n_spheres).copy()
+    sph["center"][0] = [np.float32(1.0) / np.float32(3.0), -0.0, np.float32(1e-42)]
+    sph["radius"][1] = np.inf
+    sph["center"][2] = [np.float32(16777217.0), np.nextafter(np.float32(1), np.float32(2)), np.float32(-3.4028235e38)]
+    tri = np.frombuffer(sc.triangles, dtype=rtmi.host.TRIANGLE_DTYPE, count=sc.n_triangles)
+    msh = np.frombuffer(sc.meshes, dtype=rtmi.host.MESH_DTYPE, count=sc.n_meshes)
+    sc = rtmi.Scene.from_records(sph, tri, msh)
+    path = tmp_path / "scene.txt"
+    sc.save(path)
+    back = rtmi.Scene.load(path)
+    assert (back.n_spheres, back.n_triangles, back.n_meshes) == (200, 60, 3)
+    assert _records(back, rtmi) == _records(sc, rtmi)
+    # the reference scene too, and an empty scene
+    ref = rtmi.reference_scene()
+    ref.save(path)
+    assert _records(rtmi.Scene.load(path), rtmi) == _records(ref, rtmi)
+    rtmi.Scene().save(path)
+    empty = rtmi.Scene.load(path)
+    assert (empty.n_spheres, empty.n_triangles, empty.n_meshes) == (0, 0, 0)
+
+
+def test_scene_file_is_readable_text_and_rejects_damage(rtmi, tmp_path):
+    path = tmp_path / "s.txt"
+    path.write_text("# hand-written\nrtmi-scene 1\n\nsphere 0 1 2 0.5  1 0.5 0.25 2 0.75\n"
+                    "tri 0 0 0  1 0 0  0 1 0   0 0 1  0 0 1  0 0 1\n"
+                    "mesh 0 1  0 0 0  1 1 0  0.9 0.9 0.9 0 0.1\n")
+    sc = rtmi.Scene.load(path)
+    s = sc.sphere_array()[0]
+    assert list(s.center) == [0.0, 1.0, 2.0] and s.radius == 0.5 and s.material.light == 2.0 and s.material.smoothness == 0.75
+    assert list(sc.triangles[0].p2)[:3] == [1.0, 0.0, 0.0] and list(sc.triangles[0].n3)[:3] == [0.0, 0.0, 1.0]
+    m = sc.meshes[0]
+    assert (m.start_triangle, m.num_triangles) == (0, 1) and list(m.bounding_point2)[:3] == [1.0, 1.0, 0.0]
+    good = path.read_text()
+    for bad in (good.replace("rtmi-scene 1", "rtmi-scene 2"),       # unknown version
+                good.replace("rtmi-scene 1\n", ""),                 # no header
+                good.replace("0.75\n", "0.75 9\n"),                 # extra field
+                good.replace("sphere 0 1 2 0.5", "sphere 0 1 2"),   # missing field
+                good.replace("mesh 0 1", "mesh 0 2"),               # range beyond the triangles
+                good + "cone 1 2 3\n"):                             # unknown record
+        path.write_text(bad)
+        with pytest.raises(rtmi.RtmiError) as e:
+            rtmi.Scene.load(path)
+        assert e.value.code == rtmi.abi.ERR_IO
+    with pytest.raises(rtmi.RtmiError):
+        rtmi.Scene.load(tmp_path / "missing.txt")
