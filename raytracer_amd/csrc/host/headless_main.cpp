@@ -1,10 +1,12 @@
 // headless_main.cpp — the reference's main() (main.cpp:11-452) without a window: build the scene of
-// main.cpp:161-185, run the frame loop of main.cpp:236-444 through the C ABI, write the picture.
-// Uses only include/rtmi.h.
+// main.cpp:161-185 (or read a scene file), run the frame loop of main.cpp:236-444 through the C ABI
+// with the camera input a script supplies instead of GLFW, write the picture.  Uses only include/rtmi.h.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -20,9 +22,10 @@ struct Options {
     float pose[5] = {0.0f, 1.0f, -1.0f, -90.0f, 0.0f};
     std::string meshes = "assets/meshes";
     std::string ppm, pfm;
-    int variant = RTMI_VARIANT_REGENERATE;
+    int variant = RTMI_VARIANT_COMPACT;
     bool batch = false;
     int move_at = -1;  // frame at which the W key is held for one frame (exercises reset-on-move)
+    std::string scene, script, resume, checkpoint;
     int device = 0;
     int quad_rule = 0;
 };
@@ -30,8 +33,53 @@ struct Options {
 void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
-              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1] [--batch]\n"
-              "              [--move-at FRAME] [--device N] [--fan]");
+              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2] [--batch]\n"
+              "              [--move-at FRAME] [--device N] [--fan]\n"
+              "              [--scene FILE]       text scene file instead of the built-in scene\n"
+              "              [--script FILE]      camera input, one line per run of frames:\n"
+              "                                   FRAMES DT KEYS MOUSE_X MOUSE_Y BUTTON2 RESET\n"
+              "                                   KEYS from W S A D F C and ^ (space) v (left shift), or -\n"
+              "              [--resume FILE] [--checkpoint FILE]   accumulation snapshots (static camera)");
+}
+
+// One line of a camera script: the input held for `frames` consecutive frames.
+struct ScriptStep {
+    uint32_t frames = 0;
+    double dt = 0.0;
+    rtmi_camera_input in{};
+    int reset = 0;
+};
+
+bool ReadScript(const std::string &path, std::vector<ScriptStep> &steps)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        ScriptStep st;
+        std::string keys;
+        int button = 0;
+        if (!(ls >> st.frames >> st.dt >> keys >> st.in.mouse_x >> st.in.mouse_y >> button >> st.reset)) return false;
+        st.in.mouse_button_2 = button;
+        for (char k : keys) {
+            switch (k) {
+            case 'W': st.in.key_w = 1; break;
+            case 'S': st.in.key_s = 1; break;
+            case 'A': st.in.key_a = 1; break;
+            case 'D': st.in.key_d = 1; break;
+            case 'F': st.in.key_f = 1; break;
+            case 'C': st.in.key_c = 1; break;
+            case '^': st.in.key_space = 1; break;
+            case 'v': st.in.key_left_shift = 1; break;
+            case '-': break;
+            default: return false;
+            }
+        }
+        steps.push_back(st);
+    }
+    return true;
 }
 
 bool Check(rtmi_ctx *ctx, int rc, const char *what)
@@ -62,28 +110,56 @@ int main(int argc, char **argv)
         else if (a == "--move-at" && need(1)) o.move_at = std::atoi(argv[++i]);
         else if (a == "--device" && need(1)) o.device = std::atoi(argv[++i]);
         else if (a == "--fan") o.quad_rule = 1;
+        else if (a == "--scene" && need(1)) o.scene = argv[++i];
+        else if (a == "--script" && need(1)) o.script = argv[++i];
+        else if (a == "--resume" && need(1)) o.resume = argv[++i];
+        else if (a == "--checkpoint" && need(1)) o.checkpoint = argv[++i];
         else { Usage(); return a == "--help" ? 0 : 2; }
     }
 
-    // scene: main.cpp:161-185
-    std::vector<rtmi_sphere> spheres(1);
-    std::memset(spheres.data(), 0, sizeof(rtmi_sphere));
-    spheres[0].center[0] = 1.0f; spheres[0].center[1] = 1.0f; spheres[0].center[2] = 0.0f;
-    spheres[0].radius = 0.5f;
-    spheres[0].material = rtmi_material{{1.0f, 1.0f, 1.0f}, 0.0f, 0.1f, 0.0f, 0.0f, 0.0f};
-    std::vector<rtmi_triangle> tris(64);
-    std::vector<rtmi_mesh> meshes(4);
+    std::vector<rtmi_sphere> spheres;
+    std::vector<rtmi_triangle> tris;
+    std::vector<rtmi_mesh> meshes;
     uint32_t nT = 0, nM = 0;
-    const rtmi_material planeMat{{1.0f, 1.0f, 1.0f}, 0.0f, 0.8f, 0.0f, 0.0f, 0.0f};
-    const rtmi_material cubeMat{{0.9f, 0.9f, 0.9f}, 0.0f, 0.1f, 0.0f, 0.0f, 0.0f};
-    const float zero[3] = {0.0f, 0.0f, 0.0f}, one[3] = {1.0f, 1.0f, 1.0f};
-    const float planeScale[3] = {2.0f, 1.0f, 2.0f}, cubeMove[3] = {-1.0f, 1.0f, 0.0f};
-    int rc = rtmi_load_model((o.meshes + "/plane.obj").c_str(), tris.data(), &nT, (uint32_t)tris.size(), meshes.data(), &nM,
-                             (uint32_t)meshes.size(), &planeMat, zero, planeScale, o.quad_rule);
-    if (rc < 0) std::fprintf(stderr, "warning: plane.obj not loaded from %s (%d)\n", o.meshes.c_str(), rc);
-    rc = rtmi_load_model((o.meshes + "/cube.obj").c_str(), tris.data(), &nT, (uint32_t)tris.size(), meshes.data(), &nM,
-                         (uint32_t)meshes.size(), &cubeMat, cubeMove, one, o.quad_rule);
-    if (rc < 0) std::fprintf(stderr, "warning: cube.obj not loaded from %s (%d)\n", o.meshes.c_str(), rc);
+    if (!o.scene.empty()) {
+        uint32_t nS = 0;
+        int rc = rtmi_scene_load(o.scene.c_str(), nullptr, &nS, 0, nullptr, &nT, 0, nullptr, &nM, 0);
+        if (rc == RTMI_OK) {
+            spheres.resize(nS + 1);
+            tris.resize(nT + 1);
+            meshes.resize(nM + 1);
+            rc = rtmi_scene_load(o.scene.c_str(), spheres.data(), &nS, nS, tris.data(), &nT, nT, meshes.data(), &nM, nM);
+        }
+        if (rc != RTMI_OK) {
+            std::fprintf(stderr, "cannot read scene file %s (%d)\n", o.scene.c_str(), rc);
+            return 1;
+        }
+        spheres.resize(nS);
+    } else {
+        // scene: main.cpp:161-185
+        spheres.resize(1);
+        std::memset(spheres.data(), 0, sizeof(rtmi_sphere));
+        spheres[0].center[0] = 1.0f; spheres[0].center[1] = 1.0f; spheres[0].center[2] = 0.0f;
+        spheres[0].radius = 0.5f;
+        spheres[0].material = rtmi_material{{1.0f, 1.0f, 1.0f}, 0.0f, 0.1f, 0.0f, 0.0f, 0.0f};
+        tris.resize(64);
+        meshes.resize(4);
+        const rtmi_material planeMat{{1.0f, 1.0f, 1.0f}, 0.0f, 0.8f, 0.0f, 0.0f, 0.0f};
+        const rtmi_material cubeMat{{0.9f, 0.9f, 0.9f}, 0.0f, 0.1f, 0.0f, 0.0f, 0.0f};
+        const float zero[3] = {0.0f, 0.0f, 0.0f}, one[3] = {1.0f, 1.0f, 1.0f};
+        const float planeScale[3] = {2.0f, 1.0f, 2.0f}, cubeMove[3] = {-1.0f, 1.0f, 0.0f};
+        int rc = rtmi_load_model((o.meshes + "/plane.obj").c_str(), tris.data(), &nT, (uint32_t)tris.size(), meshes.data(), &nM,
+                                 (uint32_t)meshes.size(), &planeMat, zero, planeScale, o.quad_rule);
+        if (rc < 0) std::fprintf(stderr, "warning: plane.obj not loaded from %s (%d)\n", o.meshes.c_str(), rc);
+        rc = rtmi_load_model((o.meshes + "/cube.obj").c_str(), tris.data(), &nT, (uint32_t)tris.size(), meshes.data(), &nM,
+                             (uint32_t)meshes.size(), &cubeMat, cubeMove, one, o.quad_rule);
+        if (rc < 0) std::fprintf(stderr, "warning: cube.obj not loaded from %s (%d)\n", o.meshes.c_str(), rc);
+    }
+    std::vector<ScriptStep> script;
+    if (!o.script.empty() && !ReadScript(o.script, script)) {
+        std::fprintf(stderr, "cannot read camera script %s\n", o.script.c_str());
+        return 1;
+    }
 
     rtmi_ctx *ctx = nullptr;
     if (!Check(nullptr, rtmi_create(o.device, o.width, o.height, &ctx), "rtmi_create")) return 1;
@@ -106,15 +182,31 @@ int main(int argc, char **argv)
         cam.moved = 0;
     }
 
+    uint32_t frames_done = 0;
+    if (!o.resume.empty() && !Check(ctx, rtmi_checkpoint_load(ctx, o.resume.c_str(), &frames_done), "rtmi_checkpoint_load")) return 1;
+
     const auto t0 = std::chrono::steady_clock::now();
-    uint32_t shown_frame_index = 0;
+    uint32_t shown_frame_index = 0, rendered = 0;
     if (o.batch) {
         rtmi_camera_input in{};
         rtmi_camera_update(&cam, 0.0, &in);
         rtmi_frame_advance(&fd, &cam, 0);  // frame_index becomes 1
-        if (!Check(ctx, rtmi_render_frames(ctx, &fd, 1, o.frames), "rtmi_render_frames")) return 1;
-        shown_frame_index = o.frames;
+        if (!Check(ctx, rtmi_render_frames(ctx, &fd, frames_done + 1, o.frames), "rtmi_render_frames")) return 1;
+        shown_frame_index = frames_done + o.frames;
+        rendered = o.frames;
+    } else if (!script.empty()) {
+        // main.cpp:236-444 with the script standing in for the window's input
+        fd.frame_index = frames_done;
+        for (const ScriptStep &st : script)
+            for (uint32_t f = 0; f < st.frames; f++) {
+                rtmi_camera_update(&cam, st.dt, &st.in);
+                rtmi_frame_advance(&fd, &cam, st.reset);
+                if (!Check(ctx, rtmi_render(ctx, &fd), "rtmi_render")) return 1;
+                shown_frame_index = fd.frame_index;
+                rendered++;
+            }
     } else {
+        fd.frame_index = frames_done;
         for (uint32_t f = 0; f < o.frames; f++) {
             rtmi_camera_input in{};
             in.key_w = ((int)f == o.move_at) ? 1 : 0;
@@ -122,15 +214,19 @@ int main(int argc, char **argv)
             rtmi_frame_advance(&fd, &cam, 0);
             if (!Check(ctx, rtmi_render(ctx, &fd), "rtmi_render")) return 1;
             shown_frame_index = fd.frame_index;
+            rendered++;
         }
     }
     if (!Check(ctx, rtmi_synchronize(ctx), "rtmi_synchronize")) return 1;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    const double paths = (double)o.width * o.height * o.frames * fd.rays_per_pixel;
+    const double paths = (double)o.width * o.height * rendered * fd.rays_per_pixel;
     std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"rays_per_pixel\": %u, \"max_bounce\": %u, "
                 "\"seconds\": %.6f, \"mpaths_per_s\": %.3f, \"frame_index\": %u}\n",
-                o.width, o.height, o.frames, fd.rays_per_pixel, fd.max_bounce_limit, secs, paths / secs / 1e6,
+                o.width, o.height, rendered, fd.rays_per_pixel, fd.max_bounce_limit, secs, paths / secs / 1e6,
                 shown_frame_index);
+
+    if (!o.checkpoint.empty() && !Check(ctx, rtmi_checkpoint_save(ctx, o.checkpoint.c_str(), shown_frame_index), "rtmi_checkpoint_save"))
+        return 1;
 
     const size_t np = (size_t)o.width * o.height;
     if (!o.ppm.empty()) {

@@ -499,3 +499,35 @@ def test_checkpoint_errors(rtmi, tmp_path):
             with pytest.raises(rtmi.RtmiError) as e:
                 r.load_checkpoint(path)
             assert e.value.code == rtmi.abi.ERR_IO
+
+
+# ---- scripted camera: motion resets the accumulation, stillness continues it ------------------------
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_scripted_camera_path_against_oracle(rtmi, oracle, variant):
+    w, h = 64, 36
+    sc, osc = rtmi.reference_scene(), oracle.reference_scene()
+    fd = rtmi.make_frame_data(w, h, sc, rtmi.BENCH_POSE, rays_per_pixel=2, max_bounce=5)
+    cam = rtmi.make_camera(w, h, rtmi.BENCH_POSE)
+    D = rtmi.driver
+    still = D.camera_input()
+    steps = [(3, 1 / 60, still, False),                                            # frames 1, 2, 3
+             (2, 0.25, D.camera_input("WDF", mouse=(40.0, -25.0), button2=True), False),   # moving: 1, 1
+             (3, 1 / 60, D.camera_input(mouse=(40.0, -25.0)), False),               # 2, 3, 4
+             (1, 1 / 60, D.camera_input(mouse=(40.0, -25.0)), True),                # reset key: 1
+             (2, 1 / 60, D.camera_input("^", mouse=(40.0, -25.0)), False),          # moving up: 1, 1
+             (2, 1 / 60, D.camera_input(mouse=(40.0, -25.0)), False)]               # 2, 3
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        log = D.replay(r, fd, cam, steps)
+        got = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8())
+    assert [f for f, *_ in log] == [1, 2, 3, 1, 1, 2, 3, 4, 1, 1, 1, 2, 3]
+    assert log[4][1] != log[2][1] and log[4][2] != log[2][2]      # the camera did move and turn
+    accum = None
+    for frame_index, pos, yaw, pitch in log:
+        ofd = oracle.frame_data(w, h, pos=pos, yaw=yaw, pitch=pitch, rpp=2, max_bounce=5, scene=osc)
+        want = oracle.render(ofd, osc, frame_index, 1, accum=accum, want_debug=False)
+        accum = want["accum"]
+    same = cases.bits_equal(got["accum"], want["accum"])
+    assert same, "accumulation differs in %d pixels" % int((got["accum"] != want["accum"]).any(axis=-1).sum())
+    assert np.array_equal(got["rgba8"], want["rgba8"])
