@@ -220,6 +220,11 @@ RTMI_API int rtmi_reset_counters(rtmi_ctx *ctx);
  * for n inputs.  op: 0 1/x, 1 sqrt, 2 log2 (library polynomial), 3 exp2 (library polynomial),
  * 4 uint32 -> float scaled by 2^-32 (input reinterpreted as uint32), 5 pow(x, y), 6 x / y. */
 RTMI_API int rtmi_selftest_math(rtmi_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
+/* The kernels replace sqrt, 1/x and x / constant by shorter instruction sequences wherever the
+ * argument is in the normal range.  This hook compares such a sequence with the general operation for
+ * EVERY binary32 bit pattern the sequence is used for.  op: 0 sqrt, 1 reciprocal, 2 division by
+ * `divisor`.  out = {patterns tested, mismatches, smallest mismatching pattern}. */
+RTMI_API int rtmi_selftest_exhaustive(rtmi_ctx *ctx, int op, float divisor, uint64_t out[3]);
 /* ClosestHit (RT.comp:338-388) of n arbitrary rays (3 floats each) against the uploaded scene, using
  * the first sphere_number spheres and mesh_number meshes: ray parameter t (FLT_MAX on a miss) and
  * primitive id per ray.  A test hook for analytic and corner-case rays. */

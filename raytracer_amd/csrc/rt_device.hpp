@@ -41,9 +41,60 @@ __device__ __forceinline__ V3 gmix(V3 a, V3 b, float t)
 {
     return mk(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t));
 }
+
+// ---- Correctly rounded sqrt, reciprocal and division by a constant for arguments in the normal
+// range, in fewer instructions than the compiler's general expansions (which also scale denormals and
+// patch special values).  Each returns exactly what sqrtf(x), 1.0f / x and x / c return for every
+// argument its range predicate admits; that is checked on the GPU for ALL admitted bit patterns
+// (k_selftest_exhaustive).  Callers send everything else through the general operation.
+constexpr float kTwoPowMinus96 = 1.2621774483536189e-29f, kTwoPow96 = 7.9228162514264338e28f;
+constexpr float kTwoPowMinus60 = 8.6736173798840355e-19f, kTwoPow60 = 1.152921504606846976e18f;
+
+// hardware estimate (within 1 ulp), then the neighbour whose residual changes sign
+__device__ __forceinline__ bool sqrt_rn_admits(float x) { return x >= kTwoPowMinus96; }  // up to and including +inf
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = (rd <= 0.0f) ? sd : s;
+    s = (ru > 0.0f) ? su : s;
+    return s;
+}
+
+// hardware estimate (within 1 ulp), one Newton step, one correction by the exact residual
+__device__ __forceinline__ bool rcp_rn_admits(float x) { return x >= kTwoPowMinus60 && x <= kTwoPow60; }
+__device__ __forceinline__ float rcp_rn(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+// x / c for a constant c with rc = 1.0f / c: product, then two corrections by the exact remainder
+__device__ __forceinline__ bool div_const_admits(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    return ax >= kTwoPowMinus60 && ax <= kTwoPow60;  // zeros excluded: the corrections would turn -0 into +0
+}
+__device__ __forceinline__ float div_const_rn(float x, float c, float rc)
+{
+    float q = x * rc;
+    float rem = __builtin_fmaf(-c, q, x);
+    q = __builtin_fmaf(rem, rc, q);
+    rem = __builtin_fmaf(-c, q, x);
+    return __builtin_fmaf(rem, rc, q);
+}
+
 __device__ __forceinline__ V3 normalize(V3 a)
 {
-    float inv = 1.0f / sqrtf(dot(a, a));
+    const float dd = dot(a, a);
+    float inv;
+    // 2^-96 <= dd <= 2^96 keeps the root within rcp_rn's range
+    if (dd >= kTwoPowMinus96 && dd <= kTwoPow96) inv = rcp_rn(sqrt_rn(dd));
+    else inv = 1.0f / sqrtf(dd);
     return a * inv;
 }
 __device__ __forceinline__ V3 reflect(V3 i, V3 n)
@@ -54,6 +105,17 @@ __device__ __forceinline__ V3 reflect(V3 i, V3 n)
 __device__ __forceinline__ float smoothstep(float e0, float e1, float x)
 {
     float t = gclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+// smoothstep with compile-time edges: the division is by a constant
+__device__ __forceinline__ float smoothstep_const(float e0, float e1, float x)
+{
+    const float c = e1 - e0, rc = 1.0f / c;  // folded at compile time for literal edges
+    const float num = x - e0;
+    float q;
+    if (div_const_admits(num)) q = div_const_rn(num, c, rc);
+    else q = num / c;
+    const float t = gclamp(q, 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
 
@@ -240,9 +302,12 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
             }
         };
         // b >= 0 makes the numerator -b - sqrt(disc) <= 0, which can never pass t > 0.0001
+        // (a discriminant below 2^-96 is outside the short square root's range: such a ray goes through the
+        // literal evaluation below)
         auto candidate = [&](float b, float disc, uint32_t i) {
             if (disc >= 0.0f && b < 0.0f) {
-                const float n = -b - sqrtf(disc);
+                ambiguous = ambiguous || !sqrt_rn_admits(disc);
+                const float n = -b - sqrt_rn(disc);
                 if (n > thr_lo && n < best_n) {
                     ambiguous = ambiguous || (n < thr_hi) || (n > best_n * 0.99999f);
                     best_n = n;
@@ -386,10 +451,10 @@ struct Sky {
 // GetEnvironmentLight, Raytracing.comp:390-406
 __device__ __forceinline__ V3 env_light(const Sky &sky, V3 d)
 {
-    float grad_t = pow_poly(smoothstep(0.0f, 0.4f, d.y), 0.35f);
+    float grad_t = pow_poly(smoothstep_const(0.0f, 0.4f, d.y), 0.35f);
     V3 grad = gmix(sky.horizon, sky.zenith, grad_t);
     float sun = pow_poly(gmax(0.0f, dot(d, sky.neg_sun)), sky.sun_focus) * sky.sun_intensity;
-    float g2s = smoothstep(-0.01f, 0.0f, d.y);
+    float g2s = smoothstep_const(-0.01f, 0.0f, d.y);
     float mask = (g2s >= 1.0f) ? 1.0f : 0.0f;
     V3 base = gmix(sky.ground, grad, g2s);
     float add = sun * mask;

@@ -415,6 +415,48 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest(int op, const float 
     out[i] = r;
 }
 
+// Compares the short exact routines of rt_device.hpp with the general operations for EVERY bit pattern
+// their range predicates admit (2^24 threads x 256 patterns).  out: {patterns tested, mismatches,
+// smallest mismatching pattern}.
+__global__ __launch_bounds__(kBlockThreads) void k_selftest_exhaustive(int op, float c, unsigned long long *__restrict__ out)
+{
+    const uint32_t tid = blockIdx.x * kBlockThreads + threadIdx.x;
+    const float rc = 1.0f / c;
+    unsigned long long tested = 0ull, bad = 0ull, first = ~0ull;
+    for (uint32_t k = 0; k < 256u; k++) {
+        const uint32_t bits = (k << 24) + tid;
+        const float x = __uint_as_float(bits);
+        bool in;
+        float a, b;
+        switch (op) {
+        case 0: in = sqrt_rn_admits(x); a = sqrt_rn(x); b = sqrtf(x); break;
+        case 1: in = rcp_rn_admits(x); a = rcp_rn(x); b = 1.0f / x; break;
+        default: in = div_const_admits(x); a = div_const_rn(x, c, rc); b = x / c; break;
+        }
+        if (in) {
+            tested++;
+            if (__float_as_uint(a) != __float_as_uint(b)) {
+                bad++;
+                if ((unsigned long long)bits < first) first = bits;
+            }
+        }
+    }
+    tested = wave_sum(tested);
+    bad = wave_sum(bad);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&out[0], tested);
+        if (bad) {
+            atomicAdd(&out[1], bad);
+            atomicMin(&out[2], first);
+        }
+    }
+}
+
 // closest hit of n arbitrary rays against the uploaded scene (test hook)
 template <bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, uint32_t n_spheres, uint32_t n_meshes,
@@ -499,6 +541,12 @@ hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, fl
 {
     const dim3 grid((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1);
     hipLaunchKernelGGL(k_resolve, grid, dim3(kBlockThreads, 1, 1), 0, stream, accum, out, n_pixels, divisor);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_selftest_exhaustive(int op, float c, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_selftest_exhaustive, dim3((1u << 24) / kBlockThreads, 1, 1), dim3(kBlockThreads, 1, 1), 0, stream, op, c, out);
     return hipGetLastError();
 }
 

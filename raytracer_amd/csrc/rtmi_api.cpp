@@ -712,6 +712,25 @@ int rtmi_selftest_math(rtmi_ctx *c, int op, const float *x, const float *y, floa
     return rc;
 }
 
+int rtmi_selftest_exhaustive(rtmi_ctx *c, int op, float divisor, uint64_t out[3])
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!out || op < 0 || op > 2 || (op == 2 && !(std::fabs(divisor) >= 1e-6f && std::fabs(divisor) <= 1e6f)))
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_selftest_exhaustive: bad arguments");
+    if (int rc = use_device(c)) return rc;
+    unsigned long long *d = nullptr;
+    const unsigned long long init[3] = {0ull, 0ull, ~0ull};
+    int rc = RTMI_OK;
+    hipError_t e = hipMalloc(&d, sizeof init);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rt_launch_selftest_exhaustive(op, divisor, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof init, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_exhaustive: %s", hipGetErrorString(e));
+    (void)hipFree(d);
+    return rc;
+}
+
 int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh_number, const float *origins,
                               const float *directions, size_t n, float *t_out, uint32_t *prim_out)
 {

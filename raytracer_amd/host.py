@@ -344,6 +344,13 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
+    def selftest_exhaustive(self, op, divisor=1.0):
+        """(patterns tested, mismatches, smallest mismatching bit pattern) of a short exact routine
+        against the general operation: op 0 sqrt, 1 reciprocal, 2 division by `divisor`."""
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self._lib.rtmi_selftest_exhaustive(self._ctx, op, divisor, out.ctypes.data))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def selftest_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)

@@ -531,3 +531,14 @@ def test_scripted_camera_path_against_oracle(rtmi, oracle, variant):
     same = cases.bits_equal(got["accum"], want["accum"])
     assert same, "accumulation differs in %d pixels" % int((got["accum"] != want["accum"]).any(axis=-1).sum())
     assert np.array_equal(got["rgba8"], want["rgba8"])
+
+
+def test_short_exact_routines_match_for_every_admitted_input(rtmi):
+    """The kernels' short sqrt / reciprocal / division-by-constant sequences against the general
+    correctly rounded operations, for every binary32 bit pattern they are used for."""
+    with rtmi.Renderer(8, 8) as r:
+        for op, divisor, at_least in ((0, 1.0, 0x70000000), (1, 1.0, 0x3C000000),
+                                      (2, float(np.float32(0.4)), 0x78000000), (2, float(np.float32(0.01)), 0x78000000)):
+            tested, bad, first = r.selftest_exhaustive(op, divisor)
+            assert tested >= at_least, (op, divisor, tested)
+            assert bad == 0, "op %d divisor %g: %d mismatches, first at bit pattern 0x%08x" % (op, divisor, bad, first)
