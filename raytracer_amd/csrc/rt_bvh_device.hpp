@@ -60,97 +60,39 @@ __device__ __forceinline__ bool bvh_box(const float4 lo, const float4 hi, float 
     return !(tmax < 0.0f) && !(tmin > tmax) && !(tmin > t_limit);
 }
 
-// Walks one hierarchy; leaf(first, count) tests the leaf-order entries [first, first + count) and
-// updates best.  stack points at this lane's first slot; consecutive levels are stride words apart.
-template <bool COUNT, class Leaf>
-__device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes, uint32_t root, V3 o, V3 inv, float kappa,
-                                         const Hit &best, uint32_t *stack, uint32_t stride, Counters &cn, Leaf &&leaf)
-{
-    if (root == kBvhEmpty) return;
-    uint32_t ref = root;
-    int sp = 0;
-    for (;;) {
-        if (ref & kBvhLeafFlag) {
-            leaf(ref & 0x0FFFFFFFu, (ref >> 28) & 7u);
-            if (sp == 0) break;
-            ref = stack[(uint32_t)(--sp) * stride];
-        } else {
-            const float4 q0 = nodes[4 * (size_t)ref + 0];
-            const float4 q1 = nodes[4 * (size_t)ref + 1];
-            const float4 q2 = nodes[4 * (size_t)ref + 2];
-            const float4 q3 = nodes[4 * (size_t)ref + 3];
-            if (COUNT) cn.c[3] += 2u;
-            const float t_limit = best.t * kBvhTSlack;
-            float tl, tr;
-            const bool hl = bvh_box(q0, q1, q2.w, o, inv, kappa, t_limit, tl);
-            const bool hr = bvh_box(q2, q3, q3.w, o, inv, kappa, t_limit, tr);
-            const uint32_t L = __float_as_uint(q0.w), R = __float_as_uint(q1.w);
-            if (hl && hr) {
-                const bool right_first = tr < tl;
-                if (sp < kBvhStack) stack[(uint32_t)(sp++) * stride] = right_first ? L : R;
-                ref = right_first ? R : L;
-            } else if (hl) {
-                ref = L;
-            } else if (hr) {
-                ref = R;
-            } else {
-                if (sp == 0) break;
-                ref = stack[(uint32_t)(--sp) * stride];
-            }
-        }
-    }
-}
-
-// ClosestHit (Raytracing.comp:338-388) over the hierarchies of the uploaded scene.
-template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_bvh(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
-                                               Counters &cn, uint32_t *stack, uint32_t stride)
-{
+// ClosestHit (Raytracing.comp:338-388) over the hierarchies of the uploaded scene, as a resumable
+// per-lane walk.
+//
+// A lane walks, in the shader's group order, the sphere hierarchy and then the hierarchy of every mesh
+// whose box gate its ray passes.  Each trip() does ONE thing for the lane: test the two child boxes of
+// an inner node, or test one primitive of a leaf, or move on to the lane's next group.  All state is
+// in the struct (and the lane's stack slots), so a caller may stop after any trip, do other work with
+// the lanes that are done, start new rays in them, and come back: lanes of a wave are then at
+// different places of different hierarchies, for different rays, at the same time.
+struct BvhWalk {
     Hit best;
-    best.t = kFltMax;
-    best.prim = kMissId;
-    best.mat = 0;
-    best.u = 0.0f;
-    best.v = 0.0f;
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv;                  // 1 / d per component (Raytracing.comp:313-315)
+    float a;                 // dot(d, d)
+    unsigned long long gates;  // bit b: the ray enters mesh gate_base + b and has not walked it yet
+    uint32_t gate_base;      // first mesh of the current chunk of 64 gates
+    uint32_t cur_mesh, ref, leaf_pos, leaf_left;
+    int sp;
+    bool active;             // the walk has work left
+    bool walking;            // ref / leaf_left describe work inside the current group
+    bool spheres_pending, in_spheres, own_best;
+};
 
-    // RaySphere, Raytracing.comp:130-161, for the spheres of the leaves the ray reaches
-    if (n_spheres > 0) {
-        const float a = dot(d, d);
-        const float a4 = 4.0f * a;
-        const float a2 = 2.0f * a;
-        bvh_walk<COUNT>(sc.bvh_nodes, sc.bvh_sphere_root, o, inv, kBvhSphereKappa, best, stack, stride, cn,
-                        [&](uint32_t first, uint32_t count) {
-                            for (uint32_t k = 0; k < count; k++) {
-                                const uint32_t id = sc.bvh_sphere_id[first + k];
-                                if (id >= n_spheres) continue;  // not among the spheres this frame names
-                                const float4 g = sc.bvh_sphere_geom[first + k];
-                                const V3 oc = o - mk(g.x, g.y, g.z);
-                                const float b = 2.0f * dot(oc, d);
-                                const float c = dot(oc, oc) - g.w;
-                                const float disc = b * b - a4 * c;
-                                if (COUNT) {
-                                    cn.c[0]++;
-                                    if (disc >= 0.0f) cn.c[1]++;
-                                }
-                                if (disc >= 0.0f) {
-                                    const float t = (-b - sqrtf(disc)) / a2;
-                                    // the shader's loop keeps the lowest index among equal t
-                                    if (t > 0.0001f && (t < best.t || (t == best.t && id < best.prim && best.prim != kMissId))) {
-                                        best.t = t;
-                                        best.prim = id;
-                                        best.mat = id;
-                                    }
-                                }
-                            }
-                        });
-    }
-
-    // RayBox gate (Raytracing.comp:311-336, 352-356) exactly as the shader evaluates it, then
-    // RayTriangle (Raytracing.comp:286-309) for the triangles of the leaves the ray reaches
-    for (uint32_t m = 0; m < n_meshes; m++) {
-        const float4 lo = ld_uniform(sc.mesh_box, 2 * m + 0);
-        const float4 hi = ld_uniform(sc.mesh_box, 2 * m + 1);
+// RayBox gates (Raytracing.comp:311-336, 352-356) of meshes base .. base + 63, exactly as the shader
+// evaluates them.  base may differ between lanes.
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long bvh_gates(const DeviceScene &sc, uint32_t base, uint32_t n_meshes, V3 o, V3 inv,
+                                                        Counters &cn)
+{
+    unsigned long long gates = 0ull;
+    const uint32_t chunk_end = (n_meshes - base < 64u) ? n_meshes : base + 64u;
+    for (uint32_t m = base; m < chunk_end; m++) {
+        const float4 lo = sc.mesh_box[2 * m + 0];
+        const float4 hi = sc.mesh_box[2 * m + 1];
         const float t1 = (lo.x - o.x) * inv.x;
         const float t2 = (hi.x - o.x) * inv.x;
         const float t3 = (lo.y - o.y) * inv.y;
@@ -161,45 +103,204 @@ __device__ __forceinline__ Hit closest_hit_bvh(const DeviceScene &sc, uint32_t n
         const float tmax = gmin(gmin(gmax(t1, t2), gmax(t3, t4)), gmax(t5, t6));
         if (COUNT) cn.c[3]++;
         const bool inside = !(tmax < 0.0f) && !(tmin > tmax);
-        if (!inside) continue;
-        // a triangle of this mesh replaces an equal-t winner only if that winner is a higher-indexed
-        // triangle of this same mesh: earlier spheres and meshes keep their ties
-        bool own_best = false;
-        bvh_walk<COUNT>(sc.bvh_nodes, sc.bvh_mesh_root[m], o, inv, kBvhTriangleKappa, best, stack, stride, cn,
-                        [&](uint32_t first, uint32_t count) {
-                            for (uint32_t k = 0; k < count; k++) {
-                                const size_t e = (size_t)first + k;
-                                const float4 P = sc.bvh_tri_isect[4 * e + 0];
-                                const float4 AB = sc.bvh_tri_isect[4 * e + 1];
-                                const float4 AC = sc.bvh_tri_isect[4 * e + 2];
-                                const float4 N = sc.bvh_tri_isect[4 * e + 3];
-                                if (COUNT) cn.c[4]++;
-                                const V3 nrm = mk(N.x, N.y, N.z);
-                                const float det = -dot(d, nrm);
-                                if (det >= 1e-6f) {
-                                    const V3 ao = o - mk(P.x, P.y, P.z);
-                                    const V3 dao = cross(ao, d);
-                                    const float inv_det = 1.0f / det;
-                                    const float t = dot(ao, nrm) * inv_det;
-                                    const float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv_det;
-                                    const float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv_det;
-                                    const float w = 1.0f - u - v;
-                                    if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f) {
-                                        const uint32_t prim = n_spheres + sc.bvh_tri_id[e];
-                                        if (t < best.t || (own_best && t == best.t && prim < best.prim)) {
-                                            best.t = t;
-                                            best.prim = prim;
-                                            best.mat = sc.n_spheres + m;
-                                            best.u = u;
-                                            best.v = v;
-                                            own_best = true;
-                                        }
-                                    }
-                                }
-                            }
-                        });
+        gates |= inside ? (1ull << (m - base)) : 0ull;
     }
-    return best;
+    return gates;
+}
+
+// a walk with nothing to do
+__device__ __forceinline__ void bvh_idle(BvhWalk &w)
+{
+    w.best.t = kFltMax;
+    w.best.prim = kMissId;
+    w.best.mat = 0;
+    w.best.u = 0.0f;
+    w.best.v = 0.0f;
+    w.inv = mk(0.0f, 0.0f, 0.0f);
+    w.a = 0.0f;
+    w.gates = 0ull;
+    w.gate_base = 0u;
+    w.cur_mesh = 0u;
+    w.ref = kBvhEmpty;
+    w.leaf_pos = 0u;
+    w.leaf_left = 0u;
+    w.sp = 0;
+    w.active = false;
+    w.walking = false;
+    w.spheres_pending = false;
+    w.in_spheres = false;
+    w.own_best = false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void bvh_begin(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
+                                          Counters &cn)
+{
+    w.best.t = kFltMax;
+    w.best.prim = kMissId;
+    w.best.mat = 0;
+    w.best.u = 0.0f;
+    w.best.v = 0.0f;
+    w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.a = dot(d, d);
+    w.gate_base = 0u;
+    w.gates = bvh_gates<COUNT>(sc, 0u, n_meshes, o, w.inv, cn);
+    w.spheres_pending = n_spheres > 0u && sc.bvh_sphere_root != kBvhEmpty;
+    w.walking = false;
+    w.in_spheres = false;
+    w.own_best = false;
+    w.cur_mesh = 0u;
+    w.ref = kBvhEmpty;
+    w.leaf_pos = 0u;
+    w.leaf_left = 0u;
+    w.sp = 0;
+    w.active = true;
+}
+
+// One step of the lane's walk.  stack points at this lane's first slot; consecutive levels are
+// stride words apart.
+template <bool COUNT>
+__device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
+                                         Counters &cn, uint32_t *stack, uint32_t stride)
+{
+    if (!w.walking) {
+        // next group of this lane: the spheres first, then the gated meshes in index order
+        if (w.spheres_pending) {
+            w.spheres_pending = false;
+            w.in_spheres = true;
+            w.ref = sc.bvh_sphere_root;
+        } else if (w.gates != 0ull) {
+            const uint32_t b = (uint32_t)__ffsll((long long)w.gates) - 1u;
+            w.gates &= w.gates - 1ull;
+            w.cur_mesh = w.gate_base + b;
+            w.in_spheres = false;
+            w.own_best = false;
+            w.ref = sc.bvh_mesh_root[w.cur_mesh];
+            if (w.ref == kBvhEmpty) return;
+        } else if (n_meshes - w.gate_base > 64u) {
+            w.gate_base += 64u;
+            w.gates = bvh_gates<COUNT>(sc, w.gate_base, n_meshes, o, w.inv, cn);
+            return;
+        } else {
+            w.active = false;
+            return;
+        }
+        w.walking = true;
+        w.leaf_left = 0u;
+        w.sp = 0;
+    }
+
+    if (w.leaf_left == 0u && (w.ref & kBvhLeafFlag)) {
+        w.leaf_pos = w.ref & 0x0FFFFFFFu;
+        w.leaf_left = (w.ref >> 28) & 7u;
+    }
+    if (w.leaf_left != 0u) {
+        // ---- one primitive of a leaf
+        const size_t e = w.leaf_pos;
+        w.leaf_pos++;
+        w.leaf_left--;
+        if (w.in_spheres) {
+            // RaySphere, Raytracing.comp:130-161
+            const float4 g = sc.bvh_sphere_geom[e];
+            const V3 oc = o - mk(g.x, g.y, g.z);
+            const float b = 2.0f * dot(oc, d);
+            const float c = dot(oc, oc) - g.w;
+            const float disc = b * b - (4.0f * w.a) * c;
+            if (disc >= 0.0f) {
+                const float t = (-b - sqrtf(disc)) / (2.0f * w.a);
+                if (t > 0.0001f && t <= w.best.t) {
+                    // the shader's loop keeps the lowest index among equal t
+                    const uint32_t id = sc.bvh_sphere_id[e];
+                    if (id < n_spheres && (t < w.best.t || (id < w.best.prim && w.best.prim != kMissId))) {
+                        w.best.t = t;
+                        w.best.prim = id;
+                        w.best.mat = id;
+                    }
+                }
+            }
+            if (COUNT) {
+                // spheres beyond the count this frame names are not tests the shader makes
+                if (sc.bvh_sphere_id[e] < n_spheres) {
+                    cn.c[0]++;
+                    if (disc >= 0.0f) cn.c[1]++;
+                }
+            }
+        } else {
+            // RayTriangle, Raytracing.comp:286-309
+            const float4 P = sc.bvh_tri_isect[4 * e + 0];
+            const float4 AB = sc.bvh_tri_isect[4 * e + 1];
+            const float4 AC = sc.bvh_tri_isect[4 * e + 2];
+            const float4 N = sc.bvh_tri_isect[4 * e + 3];
+            if (COUNT) cn.c[4]++;
+            const V3 nrm = mk(N.x, N.y, N.z);
+            const float det = -dot(d, nrm);
+            if (det >= 1e-6f) {
+                const V3 ao = o - mk(P.x, P.y, P.z);
+                const V3 dao = cross(ao, d);
+                const float inv_det = 1.0f / det;
+                const float t = dot(ao, nrm) * inv_det;
+                const float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv_det;
+                const float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv_det;
+                const float wgt = 1.0f - u - v;
+                if (t >= 0.0f && u >= 0.0f && v >= 0.0f && wgt >= 0.0f && t <= w.best.t) {
+                    // a triangle of this mesh replaces an equal-t winner only if that winner is a
+                    // higher-indexed triangle of this same mesh: earlier groups keep their ties
+                    const uint32_t prim = n_spheres + sc.bvh_tri_id[e];
+                    if (t < w.best.t || (w.own_best && prim < w.best.prim)) {
+                        w.best.t = t;
+                        w.best.prim = prim;
+                        w.best.mat = sc.n_spheres + w.cur_mesh;
+                        w.best.u = u;
+                        w.best.v = v;
+                        w.own_best = true;
+                    }
+                }
+            }
+        }
+        if (w.leaf_left == 0u) {
+            if (w.sp == 0) w.walking = false;
+            else w.ref = stack[(uint32_t)(--w.sp) * stride];
+        }
+    } else {
+        // ---- one inner node: both child boxes
+        const float4 *__restrict__ nodes = sc.bvh_nodes;
+        const float4 q0 = nodes[4 * (size_t)w.ref + 0];
+        const float4 q1 = nodes[4 * (size_t)w.ref + 1];
+        const float4 q2 = nodes[4 * (size_t)w.ref + 2];
+        const float4 q3 = nodes[4 * (size_t)w.ref + 3];
+        if (COUNT) cn.c[3] += 2u;
+        const float kappa = w.in_spheres ? kBvhSphereKappa : kBvhTriangleKappa;
+        const float t_limit = w.best.t * kBvhTSlack;
+        float tl, tr;
+        const bool hl = bvh_box(q0, q1, q2.w, o, w.inv, kappa, t_limit, tl);
+        const bool hr = bvh_box(q2, q3, q3.w, o, w.inv, kappa, t_limit, tr);
+        const uint32_t L = __float_as_uint(q0.w), R = __float_as_uint(q1.w);
+        if (hl && hr) {
+            const bool right_first = tr < tl;
+            stack[(uint32_t)w.sp * stride] = right_first ? L : R;  // sp < kBvhStack: one entry per level
+            w.sp++;
+            w.ref = right_first ? R : L;
+        } else if (hl) {
+            w.ref = L;
+        } else if (hr) {
+            w.ref = R;
+        } else if (w.sp == 0) {
+            w.walking = false;
+        } else {
+            w.ref = stack[(uint32_t)(--w.sp) * stride];
+        }
+    }
+}
+
+// The whole walk of one ray.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_bvh(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
+                                               Counters &cn, uint32_t *stack, uint32_t stride)
+{
+    BvhWalk w;
+    bvh_begin<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn);
+    while (w.active) bvh_trip<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
+    return w.best;
 }
 
 }  // namespace rtd

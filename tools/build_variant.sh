@@ -10,5 +10,5 @@ mkdir -p "$ROOT/scratch"
     -I"$ROOT/include" -I"$ROOT/raytracer_amd/csrc" $EXTRA \
     -c "$ROOT/raytracer_amd/csrc/rt_kernels.hip" -o "$ROOT/scratch/rt_kernels_$NAME.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$ROOT/scratch/librtmi_$NAME.so" \
-    "$ROOT/scratch/rt_kernels_$NAME.o" "$ROOT/build/rtmi/rtmi_api.o" "$ROOT/build/rtmi/rt_host.o" "$ROOT/build/rtmi/rt_host_c.o"
+    "$ROOT/scratch/rt_kernels_$NAME.o" $(ls "$ROOT"/build/rtmi/*.o | grep -v rt_kernels.o)
 echo "built scratch/librtmi_$NAME.so"
