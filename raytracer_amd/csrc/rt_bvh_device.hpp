@@ -77,9 +77,17 @@ struct BvhWalk {
     uint32_t gate_base;      // first mesh of the current chunk of 64 gates
     uint32_t cur_mesh, ref, leaf_pos, leaf_left;
     int sp;
-    bool active;             // the walk has work left
-    bool walking;            // ref / leaf_left describe work inside the current group
-    bool spheres_pending, in_spheres, own_best;
+    // per-lane flags in one register (as separate bools they would each occupy a lane-mask register pair)
+    uint32_t flags;
+    static constexpr uint32_t kActive = 1u;          // the walk has work left
+    static constexpr uint32_t kWalking = 2u;         // ref / leaf_left describe work inside the current group
+    static constexpr uint32_t kSpheresPending = 4u;  // the sphere hierarchy has not been walked yet
+    static constexpr uint32_t kInSpheres = 8u;       // the current group is the sphere hierarchy
+    static constexpr uint32_t kOwnBest = 16u;        // best is a triangle of the current mesh
+    __device__ __forceinline__ bool is(uint32_t f) const { return (flags & f) != 0u; }
+    __device__ __forceinline__ void set(uint32_t f) { flags |= f; }
+    __device__ __forceinline__ void clear(uint32_t f) { flags &= ~f; }
+    __device__ __forceinline__ bool active() const { return is(kActive); }
 };
 
 // RayBox gates (Raytracing.comp:311-336, 352-356) of meshes base .. base + 63, exactly as the shader
@@ -125,11 +133,7 @@ __device__ __forceinline__ void bvh_idle(BvhWalk &w)
     w.leaf_pos = 0u;
     w.leaf_left = 0u;
     w.sp = 0;
-    w.active = false;
-    w.walking = false;
-    w.spheres_pending = false;
-    w.in_spheres = false;
-    w.own_best = false;
+    w.flags = 0u;
 }
 
 template <bool COUNT>
@@ -145,16 +149,12 @@ __device__ __forceinline__ void bvh_begin(BvhWalk &w, const DeviceScene &sc, uin
     w.a = dot(d, d);
     w.gate_base = 0u;
     w.gates = bvh_gates<COUNT>(sc, 0u, n_meshes, o, w.inv, cn);
-    w.spheres_pending = n_spheres > 0u && sc.bvh_sphere_root != kBvhEmpty;
-    w.walking = false;
-    w.in_spheres = false;
-    w.own_best = false;
+    w.flags = BvhWalk::kActive | ((n_spheres > 0u && sc.bvh_sphere_root != kBvhEmpty) ? BvhWalk::kSpheresPending : 0u);
     w.cur_mesh = 0u;
     w.ref = kBvhEmpty;
     w.leaf_pos = 0u;
     w.leaf_left = 0u;
     w.sp = 0;
-    w.active = true;
 }
 
 // One step of the lane's walk.  stack points at this lane's first slot; consecutive levels are
@@ -163,18 +163,17 @@ template <bool COUNT>
 __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
                                          Counters &cn, uint32_t *stack, uint32_t stride)
 {
-    if (!w.walking) {
+    if (!w.is(BvhWalk::kWalking)) {
         // next group of this lane: the spheres first, then the gated meshes in index order
-        if (w.spheres_pending) {
-            w.spheres_pending = false;
-            w.in_spheres = true;
+        if (w.is(BvhWalk::kSpheresPending)) {
+            w.clear(BvhWalk::kSpheresPending);
+            w.set(BvhWalk::kInSpheres);
             w.ref = sc.bvh_sphere_root;
         } else if (w.gates != 0ull) {
             const uint32_t b = (uint32_t)__ffsll((long long)w.gates) - 1u;
             w.gates &= w.gates - 1ull;
             w.cur_mesh = w.gate_base + b;
-            w.in_spheres = false;
-            w.own_best = false;
+            w.clear(BvhWalk::kInSpheres | BvhWalk::kOwnBest);
             w.ref = sc.bvh_mesh_root[w.cur_mesh];
             if (w.ref == kBvhEmpty) return;
         } else if (n_meshes - w.gate_base > 64u) {
@@ -182,10 +181,10 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
             w.gates = bvh_gates<COUNT>(sc, w.gate_base, n_meshes, o, w.inv, cn);
             return;
         } else {
-            w.active = false;
+            w.clear(BvhWalk::kActive);
             return;
         }
-        w.walking = true;
+        w.set(BvhWalk::kWalking);
         w.leaf_left = 0u;
         w.sp = 0;
     }
@@ -199,7 +198,7 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
         const size_t e = w.leaf_pos;
         w.leaf_pos++;
         w.leaf_left--;
-        if (w.in_spheres) {
+        if (w.is(BvhWalk::kInSpheres)) {
             // RaySphere, Raytracing.comp:130-161
             const float4 g = sc.bvh_sphere_geom[e];
             const V3 oc = o - mk(g.x, g.y, g.z);
@@ -246,19 +245,19 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
                     // a triangle of this mesh replaces an equal-t winner only if that winner is a
                     // higher-indexed triangle of this same mesh: earlier groups keep their ties
                     const uint32_t prim = n_spheres + sc.bvh_tri_id[e];
-                    if (t < w.best.t || (w.own_best && prim < w.best.prim)) {
+                    if (t < w.best.t || (w.is(BvhWalk::kOwnBest) && prim < w.best.prim)) {
                         w.best.t = t;
                         w.best.prim = prim;
                         w.best.mat = sc.n_spheres + w.cur_mesh;
                         w.best.u = u;
                         w.best.v = v;
-                        w.own_best = true;
+                        w.set(BvhWalk::kOwnBest);
                     }
                 }
             }
         }
         if (w.leaf_left == 0u) {
-            if (w.sp == 0) w.walking = false;
+            if (w.sp == 0) w.clear(BvhWalk::kWalking);
             else w.ref = stack[(uint32_t)(--w.sp) * stride];
         }
     } else {
@@ -269,7 +268,7 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
         const float4 q2 = nodes[4 * (size_t)w.ref + 2];
         const float4 q3 = nodes[4 * (size_t)w.ref + 3];
         if (COUNT) cn.c[3] += 2u;
-        const float kappa = w.in_spheres ? kBvhSphereKappa : kBvhTriangleKappa;
+        const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
         const float t_limit = w.best.t * kBvhTSlack;
         float tl, tr;
         const bool hl = bvh_box(q0, q1, q2.w, o, w.inv, kappa, t_limit, tl);
@@ -285,7 +284,7 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
         } else if (hr) {
             w.ref = R;
         } else if (w.sp == 0) {
-            w.walking = false;
+            w.clear(BvhWalk::kWalking);
         } else {
             w.ref = stack[(uint32_t)(--w.sp) * stride];
         }
@@ -299,7 +298,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const DeviceScene &sc, uint32_t n
 {
     BvhWalk w;
     bvh_begin<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn);
-    while (w.active) bvh_trip<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
+    while (w.active()) bvh_trip<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
     return w.best;
 }
 
