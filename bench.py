@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_spheres", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1, 16 for c5)")
     ap.add_argument("--variant", type=int, default=2,
                     help="0 nested megakernel, 1 regenerating megakernel, 2 classify + wave-cooperative paths (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,7 +136,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     scene_name, width, height, max_bounce = WORKLOADS[args.workload]
-    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 4}.get(args.workload, 256)
+    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 16}.get(args.workload, 256)
     scene, pose = build_scene(R, scene_name)
     fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
     total_frames = frames * world

@@ -193,14 +193,28 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
         w.leaf_pos = w.ref & 0x0FFFFFFFu;
         w.leaf_left = (w.ref >> 28) & 7u;
     }
-    if (w.leaf_left != 0u) {
+    // One fetch for whatever the lane does on this trip, issued before the lanes part ways: an inner
+    // node (4 x 16 bytes), a triangle's intersection record (4 x 16 bytes) or a sphere (16 bytes, read
+    // four times).  A wave whose lanes are in different modes then waits for memory once per trip,
+    // not once per mode.
+    const bool in_leaf = w.leaf_left != 0u;
+    const bool sphere_leaf = in_leaf && w.is(BvhWalk::kInSpheres);
+    const size_t e = w.leaf_pos;
+    const float4 *__restrict__ rec = in_leaf ? (sphere_leaf ? sc.bvh_sphere_geom + e : sc.bvh_tri_isect + 4 * e)
+                                             : sc.bvh_nodes + 4 * (size_t)w.ref;
+    const uint32_t step = sphere_leaf ? 0u : 1u;
+    const float4 q0 = rec[0];
+    const float4 q1 = rec[step];
+    const float4 q2 = rec[2u * step];
+    const float4 q3 = rec[3u * step];
+
+    if (in_leaf) {
         // ---- one primitive of a leaf
-        const size_t e = w.leaf_pos;
         w.leaf_pos++;
         w.leaf_left--;
-        if (w.is(BvhWalk::kInSpheres)) {
+        if (sphere_leaf) {
             // RaySphere, Raytracing.comp:130-161
-            const float4 g = sc.bvh_sphere_geom[e];
+            const float4 g = q0;
             const V3 oc = o - mk(g.x, g.y, g.z);
             const float b = 2.0f * dot(oc, d);
             const float c = dot(oc, oc) - g.w;
@@ -226,10 +240,7 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
             }
         } else {
             // RayTriangle, Raytracing.comp:286-309
-            const float4 P = sc.bvh_tri_isect[4 * e + 0];
-            const float4 AB = sc.bvh_tri_isect[4 * e + 1];
-            const float4 AC = sc.bvh_tri_isect[4 * e + 2];
-            const float4 N = sc.bvh_tri_isect[4 * e + 3];
+            const float4 P = q0, AB = q1, AC = q2, N = q3;
             if (COUNT) cn.c[4]++;
             const V3 nrm = mk(N.x, N.y, N.z);
             const float det = -dot(d, nrm);
@@ -262,11 +273,6 @@ __device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint
         }
     } else {
         // ---- one inner node: both child boxes
-        const float4 *__restrict__ nodes = sc.bvh_nodes;
-        const float4 q0 = nodes[4 * (size_t)w.ref + 0];
-        const float4 q1 = nodes[4 * (size_t)w.ref + 1];
-        const float4 q2 = nodes[4 * (size_t)w.ref + 2];
-        const float4 q3 = nodes[4 * (size_t)w.ref + 3];
         if (COUNT) cn.c[3] += 2u;
         const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
         const float t_limit = w.best.t * kBvhTSlack;

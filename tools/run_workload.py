@@ -12,7 +12,7 @@ WORKLOADS = {"c2_spheres": ("spheres", 1920, 1080, 8), "c3_mesh": ("reference", 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2_spheres"
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-frames = int(sys.argv[4]) if len(sys.argv) > 4 else (4 if name.startswith("c5") else 256)
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else (16 if name.startswith("c5") else 256)
 accel = {"auto": R.abi.ACCEL_AUTO, "none": R.abi.ACCEL_NONE, "bvh": R.abi.ACCEL_BVH}[sys.argv[5] if len(sys.argv) > 5 else "auto"]
 scene_name, w, h, mb = WORKLOADS[name]
 pose = R.BENCH_POSE
