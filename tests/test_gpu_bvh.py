@@ -50,7 +50,7 @@ def _random_rays(seed, n, extent, far=1.0):
 
 def test_auto_mode_threshold(rtmi):
     small = rtmi.sphere_scene()
-    big, _ = _small_stress(rtmi, n_spheres=300, grid=(0, 0), n_meshes=0)
+    big, _ = _small_stress(rtmi, n_spheres=500, grid=(0, 0), n_meshes=0)
     with rtmi.Renderer(8, 8) as r:
         r.upload_scene(small)
         assert r.acceleration() == rtmi.abi.ACCEL_NONE
