@@ -364,9 +364,11 @@ void orc_closest_hit(uint32_t sphere_count, uint32_t mesh_count,
     memset(&fd, 0, sizeof fd);
     fd.sphere_count = sphere_count;
     fd.mesh_count = mesh_count;
-    counters_t cn;
-    memset(&cn, 0, sizeof cn);
+    /* rays are independent: threads split them (large scenes make one ray cost milliseconds) */
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < n; i++) {
+        counters_t cn;
+        memset(&cn, 0, sizeof cn);
         hit_info h = closest_hit(&fd, v3_from(origins + 3 * i), v3_from(dirs + 3 * i), spheres, tris, meshes, &cn);
         t_out[i] = h.dist;
         prim_out[i] = h.prim;

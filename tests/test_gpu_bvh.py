@@ -189,3 +189,36 @@ def test_degenerate_scenes(rtmi, oracle):
     for ns, nm in ((6, 2), (1, 1), (2, 0), (0, 2)):
         bvh = _hits(rtmi, sc, rtmi.abi.ACCEL_BVH, o, d, ns, nm)
         _assert_rays_equal(bvh, oracle.closest_hit(osc, o, d, ns, nm), "degenerate %d/%d" % (ns, nm))
+
+
+def test_full_size_stress_scene(rtmi, oracle):
+    """The 10^6-sphere + 10^6-triangle scene itself: closest hits of random rays against the oracle's
+    exhaustive loops (a few thousand rays are affordable), and two properties that need no oracle: the
+    nested-loop kernel (one uninterrupted walk per segment) and the wave-cooperative kernel (walks
+    stopped and resumed) give the same image, and so does splitting the frames over two launches."""
+    sc, pose = rtmi.scenes.stress_scene()
+    assert (sc.n_spheres, sc.n_triangles, sc.n_meshes) == (1000000, 1000000, 16)
+    osc = oracle.Scene.from_product(sc)
+    o, d = _random_rays(11, 3000, 50.0)
+    w, h = 96, 54
+    fd = rtmi.make_frame_data(w, h, sc, pose=pose, rays_per_pixel=1, max_bounce=16)
+    out = {}
+    for variant in (0, 2):
+        with rtmi.Renderer(w, h, variant=variant) as r:
+            r.upload_scene(sc)
+            assert r.acceleration() == rtmi.abi.ACCEL_BVH
+            if variant == 2:
+                rays = r.selftest_closest_hit(sc.n_spheres, sc.n_meshes, o, d)
+            r.enable_validation(True)
+            r.render_frames(fd, 1, 4)
+            out[variant] = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                                chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state())
+            if variant == 2:
+                r.render_frames(fd, 1, 1)
+                r.render_frames(fd, 2, 3)
+                out["split"] = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8())
+    assert_same(out[2], out[0])
+    assert_same(out["split"], out[2], keys=("rgba8",))
+    assert int((out[2]["prim_id"] != rtmi.abi.MISS_ID).sum()) > w * h // 2
+    assert int((rays[1] != rtmi.abi.MISS_ID).sum()) > 500
+    _assert_rays_equal(rays, oracle.closest_hit(osc, o, d), "full stress scene")
