@@ -266,7 +266,7 @@ RTMI_API int rtmi_scene_load(const char *path, rtmi_sphere *spheres, uint32_t *n
  * {left box lo, left ref} {left box hi, right ref} {right box lo, 0} {right box hi, 0} to nodes_out,
  * the leaf order (leaf position -> box index) to order_out and the root reference to root_out, and
  * returns the number of nodes.  A reference is an inner node index, or a leaf: bit 31 set, bits 28-30
- * the count (1..4), bits 0-27 the first leaf position counted from leaf_base; 0xFFFFFFFF for n = 0.
+ * the count (1..2), bits 0-27 the first leaf position counted from leaf_base; 0xFFFFFFFF for n = 0.
  * No counterpart in the reference. */
 RTMI_API int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nodes_out, size_t nodes_bytes,
                             uint32_t *order_out, uint32_t *root_out);

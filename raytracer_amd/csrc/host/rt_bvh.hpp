@@ -25,8 +25,9 @@ static_assert(sizeof(BvhNode) == 64, "node is 64 bytes");
 // leaf-ordered primitive arrays).  kEmptyRef marks "no primitives".
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
-constexpr uint32_t kLeafSize = 4;
-constexpr int kMaxDepth = 24;  // inner-node levels = entries of the traversal stack; enough for 2^26 primitives
+constexpr uint32_t kLeafSize = 2;  // measured on the 10^6 + 10^6 scene: 1 -> 239 ms, 2 -> 241, 3 -> 246, 4 -> 252, 6 -> 271
+constexpr int kMaxDepth = 24;  // inner-node levels = entries of the traversal stack
+constexpr uint64_t kMaxPrimitives = (uint64_t)kLeafSize << kMaxDepth;  // what a balanced tree of that depth holds
 
 struct PrimBox {
     float lo[3], hi[3];
@@ -39,7 +40,7 @@ struct PrimBox {
 // range is halved.  Leaves hold at most kLeafSize primitives.  Appends inner nodes to `nodes`,
 // returns the root reference, and fills order[k] = index of the primitive at leaf position k
 // (order is local to this call: 0..n-1).  Leaf references count from leaf_base, so that several
-// hierarchies can share one leaf-ordered primitive array (n at most 2^26, leaf_base + n below 2^28).
+// hierarchies can share one leaf-ordered primitive array (n at most kMaxPrimitives, leaf_base + n below 2^28).
 uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes, std::vector<uint32_t> &order,
                   uint32_t leaf_base);
 

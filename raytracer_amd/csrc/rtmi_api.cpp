@@ -229,8 +229,9 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     if (want_bvh) {
         uint64_t leaf_total = 0;
         for (uint32_t m = 0; m < nM; m++) leaf_total += (uint32_t)meshes[m].num_triangles;
-        if (nS > (1u << 26) || leaf_total > (1u << 26))
-            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than 2^26 primitives in the hierarchies");
+        if (nS > rtmi::kMaxPrimitives || leaf_total > rtmi::kMaxPrimitives)
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than %llu primitives in a hierarchy",
+                        (unsigned long long)rtmi::kMaxPrimitives);
         try {
             std::vector<rtmi::PrimBox> boxes(nS);
             for (uint32_t i = 0; i < nS; i++) {

@@ -25,7 +25,7 @@ def walk(nodes, order, boxes, ref, leaf_base, seen, depth=1):
     """Returns (lo, hi, depth) of the subtree; checks every stored child box against its contents."""
     if ref & LEAF:
         first, count = (ref & 0x0FFFFFFF) - leaf_base, (ref >> 28) & 7
-        assert 1 <= count <= 4
+        assert 1 <= count <= 2
         ids = order[first:first + count]
         seen.extend(int(i) for i in ids)
         b = boxes[ids]
