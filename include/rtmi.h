@@ -97,9 +97,13 @@ typedef enum rtmi_status {
 typedef enum rtmi_variant {
     RTMI_VARIANT_MEGAKERNEL = 0,   /* one lane per pixel, frame / sample / bounce loops nested as in RT.comp:464-468, 413 */
     RTMI_VARIANT_REGENERATE = 1,   /* one lane per pixel, single segment loop; a lane that ends a path starts its next one */
-    RTMI_VARIANT_COMPACT    = 2    /* default: the primary segment (identical for every sample of a pixel, RT.comp:449-453)
+    RTMI_VARIANT_COMPACT    = 2,   /* the primary segment (identical for every sample of a pixel, RT.comp:449-453)
                                       is evaluated once per launch; pixels that see only sky are finished at once, the
                                       others are stream-compacted (wave ballot + prefix count) and traced by dense waves */
+    RTMI_VARIANT_AUTO       = 3    /* default: per launch, COMPACT when the launch holds at least 12 paths per pixel
+                                      (frames x rays per pixel) or the scene uses a hierarchy, REGENERATE otherwise
+                                      (COMPACT spends about 0.4 ms per 1080p launch on classification, which a
+                                      one-frame launch, the reference's own calling pattern, does not earn back) */
 } rtmi_variant;
 
 /* How ClosestHit (RT.comp:338-388) finds its candidates.  The reference loops over every sphere and

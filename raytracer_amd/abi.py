@@ -19,6 +19,7 @@ MISS_ID = 0xFFFFFFFF
 VARIANT_MEGAKERNEL = 0
 VARIANT_REGENERATE = 1
 VARIANT_COMPACT = 2
+VARIANT_AUTO = 3
 
 ACCEL_AUTO = 0
 ACCEL_NONE = 1

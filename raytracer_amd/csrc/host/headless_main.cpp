@@ -22,7 +22,7 @@ struct Options {
     float pose[5] = {0.0f, 1.0f, -1.0f, -90.0f, 0.0f};
     std::string meshes = "assets/meshes";
     std::string ppm, pfm;
-    int variant = RTMI_VARIANT_COMPACT;
+    int variant = RTMI_VARIANT_AUTO;
     bool batch = false;
     int move_at = -1;  // frame at which the W key is held for one frame (exercises reset-on-move)
     std::string scene, script, resume, checkpoint;
@@ -33,7 +33,7 @@ struct Options {
 void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
-              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2] [--batch]\n"
+              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3] [--batch]\n"
               "              [--move-at FRAME] [--device N] [--fan]\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
               "              [--script FILE]      camera input, one line per run of frames:\n"

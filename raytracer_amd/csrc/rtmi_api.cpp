@@ -30,7 +30,7 @@ static_assert(sizeof(rtmi_triangle) == 96, "triangle is 96 bytes");
 struct rtmi_ctx {
     int device = 0;
     uint32_t width = 0, height = 0;
-    int variant = RTMI_VARIANT_COMPACT;
+    int variant = RTMI_VARIANT_AUTO;
     bool validate = false;
     std::string err;
 
@@ -439,6 +439,12 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.counters = c->counters;
 
     int variant = c->variant;
+    if (variant == RTMI_VARIANT_AUTO) {
+        // measured at 1080p: REGENERATE is ahead up to 8 paths per pixel per launch, COMPACT from 16 on;
+        // with a hierarchy only COMPACT's kernel lets finished lanes go on while others still walk
+        const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
+        variant = (c->bvh_active || paths_per_pixel >= 12) ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
+    }
     hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;
     if (c->ev_logging) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -469,7 +475,8 @@ int rtmi_render(rtmi_ctx *c, const rtmi_frame_data *fd)
 int rtmi_set_variant(rtmi_ctx *c, int variant)
 {
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
-    if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE && variant != RTMI_VARIANT_COMPACT)
+    if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE && variant != RTMI_VARIANT_COMPACT &&
+        variant != RTMI_VARIANT_AUTO)
         return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_variant: variant %d not available", variant);
     c->variant = variant;
     return RTMI_OK;

@@ -203,7 +203,7 @@ def make_frame_data(width, height, scene=None, pose=DEFAULT_POSE, rays_per_pixel
 class Renderer:
     """One context = one GPU, one image extent (rtmi_create ... rtmi_destroy)."""
 
-    def __init__(self, width, height, device=0, variant=abi.VARIANT_COMPACT):
+    def __init__(self, width, height, device=0, variant=abi.VARIANT_AUTO):
         self._lib = abi.load()
         self._ctx = C.c_void_p()
         self.width, self.height = int(width), int(height)
