@@ -271,7 +271,12 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
         off_mroot = align_up(off_btid + tri_order.size() * 4, 256);
         total = align_up(off_mroot + (size_t)nM * 4, 256) + 256;
     }
-    std::vector<unsigned char> blob(total, 0);
+    std::vector<unsigned char> blob;
+    try {
+        blob.assign(total, 0);
+    } catch (const std::bad_alloc &) {
+        return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation of %zu bytes failed", total);
+    }
     float *sph = reinterpret_cast<float *>(blob.data() + off_sph);
     float *tri = reinterpret_cast<float *>(blob.data() + off_tri);
     float *shd = reinterpret_cast<float *>(blob.data() + off_shd);
