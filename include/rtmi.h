@@ -103,7 +103,11 @@ typedef enum rtmi_variant {
     RTMI_VARIANT_AUTO       = 3    /* default: per launch, COMPACT when the launch holds at least 12 paths per pixel
                                       (frames x rays per pixel) or the scene uses a hierarchy, REGENERATE otherwise
                                       (COMPACT spends about 0.4 ms per 1080p launch on classification, which a
-                                      one-frame launch, the reference's own calling pattern, does not earn back) */
+                                      one-frame launch, the reference's own calling pattern, does not earn back).
+                                      While the uniform block (apart from frame_index) and the scene stay the same
+                                      from launch to launch, AUTO also keeps the classification and the primary hits
+                                      of the first such launch and lets later launches of 8+ paths per pixel start
+                                      from them; results are the same bits either way */
 } rtmi_variant;
 
 /* How ClosestHit (RT.comp:338-388) finds its candidates.  The reference loops over every sphere and

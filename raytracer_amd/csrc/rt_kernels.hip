@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
 // appended to hit_list: the wave ballots its hit lanes, one lane reserves popcount slots with a single
 // atomic, and each hit lane takes the slot given by the count of hit lanes below it.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE, bool BVH>
+template <bool VALIDATE, bool BVH, bool STORE = false>
 __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p)
 {
     RT_BVH_STACK(kBlockThreads);
@@ -335,6 +335,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
     if (s.in_range) {
         const Hit h0 = scene_hit<VALIDATE, BVH>(sc, nS, nM, s.origin, s.dir, seg, bvh_stack, bvh_stride);
         hit = h0.prim != kMissId;
+        if (STORE && hit) {
+            const size_t px = (size_t)s.y * p.width + s.x;
+            p.primary[px] = make_float4(h0.t, h0.u, h0.v, __uint_as_float(h0.prim));
+            p.primary_mat[px] = h0.mat;
+        }
     }
 
     const unsigned long long mask = __ballot(hit);
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
         V3 frame_light = mk(0.0f, 0.0f, 0.0f);
         for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
         frame_light = average_samples(frame_light, p);
+        if (STORE) p.primary[(size_t)s.y * p.width + s.x] = make_float4(frame_light.x, frame_light.y, frame_light.z, __uint_as_float(kMissId));
         for (uint32_t f = 0; f < p.n_frames; f++) sum = (p.first_frame + f == 1u) ? frame_light : sum + frame_light;
         if (VALIDATE) {
             for (uint32_t f = 0; f < p.n_frames; f++) {
@@ -378,6 +384,27 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
 
 // Variant 2, second kernel: wave-cooperative tracing of the compacted pixels.
 #include "rt_paths.inc"
+
+// Variant 2 with a stored primary segment: the pixels whose primary ray leaves the scene add the stored
+// per-frame radiance, frame by frame as the shader would (Raytracing.comp:471-479).
+__global__ __launch_bounds__(kBlockThreads) void k_sky_add(const RenderParams p)
+{
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= p.width * p.height) return;
+    const float4 c = p.primary[i];
+    if (__float_as_uint(c.w) != kMissId) return;
+    const V3 frame_light = mk(c.x, c.y, c.z);
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    if (p.first_frame != 1u) {
+        const float4 a = p.accum[i];
+        sum = mk(a.x, a.y, a.z);
+    }
+    for (uint32_t f = 0; f < p.n_frames; f++) sum = (p.first_frame + f == 1u) ? frame_light : sum + frame_light;
+    p.accum[i] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    const float div = (float)(p.first_frame + p.n_frames - 1u);
+    const uint32_t r = unorm8(sum.x / div), g = unorm8(sum.y / div), b = unorm8(sum.z / div);
+    p.out_rgba8[i] = r | (g << 8) | (b << 16) | 0xFF000000u;
+}
 
 // display image from an already summed accumulation image: rgba8 = unorm8(sum / divisor).  Also puts
 // the alpha of the sum back to 1 (a sum of k partial images carries alpha k).
@@ -498,7 +525,7 @@ const char *rt_kernel_name(int variant)
     }
 }
 
-hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream)
+hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)
 {
     if (p.width == 0 || p.height == 0 || p.n_frames == 0) return hipErrorInvalidValue;
     const dim3 grid((p.width + kTile - 1) / kTile, (p.height + kTile - 1) / kTile, 1);
@@ -521,15 +548,27 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
         RT_LAUNCH(k_regenerate, grid, block);
     } else if (variant == 2) {
         if (!p.hit_list || !p.hit_count) return hipErrorInvalidValue;
-        hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
+        if (cache != RT_CACHE_NONE && (validate || !p.primary || !p.primary_mat)) return hipErrorInvalidValue;
         // one single-wave workgroup per 64 list entries; the list length is only known on the device,
         // so the grid covers the worst case and surplus workgroups leave at once
         const uint32_t n_pixels = p.width * p.height;
         const dim3 grid_paths((n_pixels + 63u) / 64u, 1, 1);
         const dim3 block_paths(kPathsThreads, 1, 1);
-        RT_LAUNCH(k_classify, grid, block);
-        RT_LAUNCH(k_paths, grid_paths, block_paths);
+        if (cache == RT_CACHE_LOAD) {
+            hipLaunchKernelGGL(k_sky_add, dim3((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1), block, 0, stream, p);
+            if (bvh) hipLaunchKernelGGL((k_paths<false, true, true>), grid_paths, block_paths, 0, stream, p);
+            else hipLaunchKernelGGL((k_paths<false, false, true>), grid_paths, block_paths, 0, stream, p);
+        } else {
+            hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+            if (cache == RT_CACHE_STORE) {
+                if (bvh) hipLaunchKernelGGL((k_classify<false, true, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_classify<false, false, true>), grid, block, 0, stream, p);
+            } else {
+                RT_LAUNCH(k_classify, grid, block);
+            }
+            RT_LAUNCH(k_paths, grid_paths, block_paths);
+        }
 #undef RT_LAUNCH
     } else {
         return hipErrorInvalidValue;

@@ -32,11 +32,21 @@ struct RenderParams {
     uint32_t *rng_state;    // validation only
     unsigned long long *counters;  // validation only, 16 entries
     uint32_t *hit_list;     // variant 2: pixels whose primary ray hits something, compacted
-    uint32_t *hit_count;    // variant 2: length of hit_list, zeroed before every launch
+    uint32_t *hit_count;    // variant 2: length of hit_list, zeroed before every launch that builds the list
+    // Primary-segment cache (variant 2, static camera): per pixel {t, u, v, bits(prim)} of the primary
+    // hit, or {r, g, b, bits(miss id)} = the radiance a sky pixel adds per frame, and the material row.
+    float4 *primary;
+    uint32_t *primary_mat;
 };
 
 const char *rt_kernel_name(int variant);
-hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream);
+// What a variant-2 launch does with the primary-segment cache
+enum RtCacheUse {
+    RT_CACHE_NONE = 0,   // evaluate every pixel's primary segment, keep nothing
+    RT_CACHE_STORE = 1,  // evaluate it and store it (also leaves hit_list / hit_count for later launches)
+    RT_CACHE_LOAD = 2    // no classification: sky pixels add their stored radiance, paths start from the stored hits
+};
+hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache = RT_CACHE_NONE);
 hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
 hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream);

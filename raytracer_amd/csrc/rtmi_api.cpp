@@ -48,6 +48,15 @@ struct rtmi_ctx {
     uint32_t *out_rgba8 = nullptr;
     uint32_t *hit_ids = nullptr, *chain_hash = nullptr, *rng_state = nullptr;
     uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list
+    // Primary-segment cache (RTMI_VARIANT_AUTO only).  With an unchanged camera, scene and frame
+    // constants every launch would classify the same pixels and find the same primary hits; they are
+    // stored once (with the work list) and later launches start from them.  The key is the whole
+    // uniform block except frame_index, plus the scene upload it was built for.
+    float4 *primary = nullptr;
+    uint32_t *primary_mat = nullptr;
+    bool cache_valid = false, last_key_set = false;
+    rtmi_frame_data cache_key{}, last_key{};
+    uint64_t scene_generation = 0, cache_generation = 0, last_generation = 0;
     unsigned long long *counters = nullptr;
 
     // scene
@@ -176,6 +185,8 @@ int rtmi_destroy(rtmi_ctx *c)
     (void)hipFree(c->hit_ids);
     (void)hipFree(c->hit_list);
     (void)hipFree(c->hit_count);
+    (void)hipFree(c->primary);
+    (void)hipFree(c->primary_mat);
     (void)hipFree(c->chain_hash);
     (void)hipFree(c->rng_state);
     (void)hipFree(c->counters);
@@ -379,6 +390,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->n_triangles = nT;
     c->n_meshes = nM;
     c->has_scene = true;
+    c->scene_generation++;  // whatever was stored for the previous scene is stale
     return RTMI_OK;
 }
 
@@ -444,12 +456,47 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.counters = c->counters;
 
     int variant = c->variant;
+    RtCacheUse cache = RT_CACHE_NONE;
     if (variant == RTMI_VARIANT_AUTO) {
         // measured at 1080p: REGENERATE is ahead up to 8 paths per pixel per launch, COMPACT from 16 on;
         // with a hierarchy only COMPACT's kernel lets finished lanes go on while others still walk
         const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
-        variant = (c->bvh_active || paths_per_pixel >= 12) ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
+        const bool compact_runs = fd->max_bounce_limit >= 2 && fd->rays_per_pixel >= 1;  // else the launcher falls back
+        rtmi_frame_data key = *fd;
+        key.frame_index = 0;
+        const bool same_as_stored = c->cache_valid && c->cache_generation == c->scene_generation &&
+                                    memcmp(&key, &c->cache_key, sizeof key) == 0;
+        const bool same_as_last = c->last_key_set && c->last_generation == c->scene_generation &&
+                                  memcmp(&key, &c->last_key, sizeof key) == 0;
+        c->last_key = key;
+        c->last_generation = c->scene_generation;
+        c->last_key_set = true;
+        // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
+        // 12 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
+        // 0.59; 2 paths: 0.23 against 0.20); below 8 the gain is within the scene-to-scene spread.
+        const bool store_pays = c->bvh_active || paths_per_pixel >= 8;
+        if (compact_runs && !c->validate && same_as_stored && store_pays) {
+            variant = RTMI_VARIANT_COMPACT;
+            cache = RT_CACHE_LOAD;
+        } else if (c->bvh_active || paths_per_pixel >= 12 || (compact_runs && !c->validate && same_as_last && store_pays)) {
+            // a camera that has stood still for two launches in a row is worth classifying once
+            variant = RTMI_VARIANT_COMPACT;
+            if (compact_runs && !c->validate) {
+                const size_t np = n_pixels(c);
+                if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
+                if (!c->primary_mat) HIP_TRY(c, hipMalloc(&c->primary_mat, np * sizeof(uint32_t)));
+                cache = RT_CACHE_STORE;
+                c->cache_key = key;
+                c->cache_generation = c->scene_generation;
+            }
+        } else {
+            variant = RTMI_VARIANT_REGENERATE;
+        }
     }
+    // any other launch of the classifying kernel rebuilds the work list for its own camera
+    if (variant == RTMI_VARIANT_COMPACT && cache != RT_CACHE_LOAD) c->cache_valid = (cache == RT_CACHE_STORE);
+    p.primary = c->primary;
+    p.primary_mat = c->primary_mat;
     hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;
     if (c->ev_logging) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -463,7 +510,7 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         c->ev_used++;
     }
     HIP_TRY(c, hipEventRecord(ev0, c->stream));
-    hipError_t e = rt_launch_render(variant, c->validate, p, c->stream);
+    hipError_t e = rt_launch_render(variant, c->validate, p, c->stream, cache);
     if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev1, c->stream));
     c->timed = !c->ev_logging;
