@@ -105,9 +105,8 @@ typedef enum rtmi_variant {
                                       (COMPACT spends about 0.4 ms per 1080p launch on classification, which a
                                       one-frame launch, the reference's own calling pattern, does not earn back).
                                       While the uniform block (apart from frame_index) and the scene stay the same
-                                      from launch to launch, AUTO also keeps the classification and the primary hits
-                                      of the first such launch and lets later launches of 8+ paths per pixel start
-                                      from them; results are the same bits either way */
+                                      from launch to launch, AUTO also keeps every pixel's primary segment and lets
+                                      later launches start from it; results are the same bits either way */
 } rtmi_variant;
 
 /* How ClosestHit (RT.comp:338-388) finds its candidates.  The reference loops over every sphere and

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
 // --------------------------------------------------------------------------------------------
 // Variant 1: one loop over segments; lanes regenerate their own next path.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE, bool BVH>
+template <bool VALIDATE, bool BVH, bool STORE = false>
 __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams p)
 {
     RT_BVH_STACK(kBlockThreads);
@@ -266,11 +266,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
             if (i == 0 && k == 0) first_prim = h.prim;
         }
         bool path_done;
+        const bool very_first = STORE && i == 0u && k == 0u && f == 0u;  // the pixel's primary segment
         if (h.prim != kMissId) {
             if (VALIDATE) {
                 cn.c[6]++;
                 if (h.prim < nS) cn.c[2]++;
                 else cn.c[5]++;
+            }
+            if (very_first) {
+                const size_t px = (size_t)s.y * p.width + s.x;
+                p.primary[px] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+                p.primary_mat[px] = h.mat;
             }
             bounce(sc, nS, h, o, d, light, thr, rng);
             i++;
@@ -278,6 +284,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
         } else {
             if (VALIDATE) cn.c[7]++;
             light = light + env_light(sky, d) * thr;
+            // a path whose primary ray leaves the scene: 0 + sky * 1, the same for every sample and frame
+            if (very_first) p.primary[(size_t)s.y * p.width + s.x] = make_float4(light.x, light.y, light.z, __uint_as_float(kMissId));
             path_done = true;
         }
         if (path_done) {
@@ -311,6 +319,107 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
         }
     }
     finish_pixel<VALIDATE>(p, s.x, s.y, s.in_range, sum, first_prim, hash, rng, cn, none, 0u);
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant 1 with a stored primary segment (static camera): one lane per pixel as in k_regenerate, but a
+// path starts at its first bounce off the stored primary hit, and a pixel whose primary ray leaves the
+// scene is finished in closed form.  Requires max_bounce >= 2 and rays_per_pixel >= 1.
+// --------------------------------------------------------------------------------------------
+template <bool BVH>
+__global__ __launch_bounds__(kBlockThreads) void k_from_primary(const RenderParams p)
+{
+    RT_BVH_STACK(kBlockThreads);
+    const PixelSetup s = pixel_setup(p);
+    const Sky sky = make_sky(p);
+    const DeviceScene &sc = p.scene;
+    const uint32_t nS = p.sphere_number, nM = p.mesh_number;
+    Counters cn, none;
+    zero(cn);
+    zero(none);
+
+    const size_t px = s.in_range ? (size_t)s.y * p.width + s.x : 0;
+    const float4 c = p.primary[px];
+    const bool primary_hit = s.in_range && __float_as_uint(c.w) != kMissId;
+    V3 sum = load_sum(p, s.x, s.y, s.in_range);
+
+    if (s.in_range && !primary_hit) {
+        const V3 light = mk(c.x, c.y, c.z);
+        V3 frame_light = mk(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
+        frame_light = average_samples(frame_light, p);
+        for (uint32_t f = 0; f < p.n_frames; f++) sum = (p.first_frame + f == 1u) ? frame_light : sum + frame_light;
+    }
+
+    // what every path of this pixel starts from
+    V3 own_pos = s.origin, own_nrm = mk(0.0f, 1.0f, 0.0f), own_color = mk(0.0f, 0.0f, 0.0f);
+    float own_emit = 0.0f, own_smooth = 0.0f;
+    if (primary_hit) {
+        Hit h0;
+        h0.t = c.x;
+        h0.u = c.y;
+        h0.v = c.z;
+        h0.prim = __float_as_uint(c.w);
+        h0.mat = p.primary_mat[px];
+        resolve_hit(sc, nS, s.origin, s.dir, h0, own_pos, own_nrm);
+        const float4 m0 = sc.materials[2 * h0.mat + 0];
+        own_color = mk(m0.x, m0.y, m0.z);
+        own_emit = m0.w;
+        own_smooth = sc.materials[2 * h0.mat + 1].x;
+    }
+    const V3 own_spec = reflect(s.dir, own_nrm);
+
+    uint32_t f = 0, k = 0, i = 0;
+    uint32_t rng = (uint32_t)s.lin + p.first_frame * 719393u;
+    V3 o = s.origin, d = s.dir;
+    V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
+    bool active = primary_hit && p.n_frames > 0u;
+
+    // the hit branch of Trace (Raytracing.comp:417-431) for the stored primary hit
+    auto start_path = [&]() {
+        const float rx = rng_next(rng) * 2.0f - 1.0f;
+        const float ry = rng_next(rng) * 2.0f - 1.0f;
+        const float rz = rng_next(rng) * 2.0f - 1.0f;
+        const V3 diffuse = normalize(own_nrm + mk(rx, ry, rz));
+        o = own_pos;
+        d = gmix(diffuse, own_spec, own_smooth);
+        const float e = 1.0f * own_emit;
+        light = mk(0.0f, 0.0f, 0.0f) + mk(e * 1.0f, e * 1.0f, e * 1.0f);
+        thr = mk(1.0f, 1.0f, 1.0f) * own_color;
+        i = 1u;
+    };
+    if (active) start_path();
+
+    while (active) {
+        const Hit h = scene_hit<false, BVH>(sc, nS, nM, o, d, cn, bvh_stack, bvh_stride);
+        bool path_done;
+        if (h.prim != kMissId) {
+            bounce(sc, nS, h, o, d, light, thr, rng);
+            i++;
+            path_done = i >= p.max_bounce;
+        } else {
+            light = light + env_light(sky, d) * thr;
+            path_done = true;
+        }
+        if (path_done) {
+            frame_light = frame_light + light;
+            k++;
+            if (k >= p.rays_per_pixel) {
+                frame_light = average_samples(frame_light, p);
+                const uint32_t fi = p.first_frame + f;
+                sum = (fi == 1u) ? frame_light : sum + frame_light;
+                frame_light = mk(0.0f, 0.0f, 0.0f);
+                k = 0;
+                f++;
+                active = f < p.n_frames;
+                if (active) rng = (uint32_t)s.lin + (p.first_frame + f) * 719393u;
+            } else {
+                rng += k;
+            }
+            if (active) start_path();
+        }
+    }
+    finish_pixel<false>(p, s.x, s.y, s.in_range, sum, kMissId, 0u, rng, cn, none, 0u);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -360,10 +469,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
         const Sky sky = make_sky(p);
         // Trace(): incomingLight = 0 + env * rayColor(1,1,1), Raytracing.comp:410-411, 434
         const V3 light = mk(0.0f, 0.0f, 0.0f) + env_light(sky, s.dir) * mk(1.0f, 1.0f, 1.0f);
+        if (STORE) p.primary[(size_t)s.y * p.width + s.x] = make_float4(light.x, light.y, light.z, __uint_as_float(kMissId));
         V3 frame_light = mk(0.0f, 0.0f, 0.0f);
         for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
         frame_light = average_samples(frame_light, p);
-        if (STORE) p.primary[(size_t)s.y * p.width + s.x] = make_float4(frame_light.x, frame_light.y, frame_light.z, __uint_as_float(kMissId));
         for (uint32_t f = 0; f < p.n_frames; f++) sum = (p.first_frame + f == 1u) ? frame_light : sum + frame_light;
         if (VALIDATE) {
             for (uint32_t f = 0; f < p.n_frames; f++) {
@@ -386,14 +495,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
 #include "rt_paths.inc"
 
 // Variant 2 with a stored primary segment: the pixels whose primary ray leaves the scene add the stored
-// per-frame radiance, frame by frame as the shader would (Raytracing.comp:471-479).
+// radiance, sample by sample and frame by frame as the shader would (Raytracing.comp:464-479).
 __global__ __launch_bounds__(kBlockThreads) void k_sky_add(const RenderParams p)
 {
     const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
     if (i >= p.width * p.height) return;
     const float4 c = p.primary[i];
     if (__float_as_uint(c.w) != kMissId) return;
-    const V3 frame_light = mk(c.x, c.y, c.z);
+    const V3 light = mk(c.x, c.y, c.z);   // one path's radiance
+    V3 frame_light = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
+    frame_light = average_samples(frame_light, p);
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     if (p.first_frame != 1u) {
         const float4 a = p.accum[i];
@@ -545,7 +657,16 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     if (variant == 0) {
         RT_LAUNCH(k_megakernel, grid, block);
     } else if (variant == 1) {
-        RT_LAUNCH(k_regenerate, grid, block);
+        if (cache != RT_CACHE_NONE && (validate || !p.primary || !p.primary_mat || p.max_bounce < 2)) return hipErrorInvalidValue;
+        if (cache == RT_CACHE_LOAD) {
+            if (bvh) hipLaunchKernelGGL((k_from_primary<true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_from_primary<false>), grid, block, 0, stream, p);
+        } else if (cache == RT_CACHE_STORE) {
+            if (bvh) hipLaunchKernelGGL((k_regenerate<false, true, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_regenerate<false, false, true>), grid, block, 0, stream, p);
+        } else {
+            RT_LAUNCH(k_regenerate, grid, block);
+        }
     } else if (variant == 2) {
         if (!p.hit_list || !p.hit_count) return hipErrorInvalidValue;
         if (cache != RT_CACHE_NONE && (validate || !p.primary || !p.primary_mat)) return hipErrorInvalidValue;

@@ -54,9 +54,9 @@ struct rtmi_ctx {
     // uniform block except frame_index, plus the scene upload it was built for.
     float4 *primary = nullptr;
     uint32_t *primary_mat = nullptr;
-    bool cache_valid = false, last_key_set = false;
-    rtmi_frame_data cache_key{}, last_key{};
-    uint64_t scene_generation = 0, cache_generation = 0, last_generation = 0;
+    bool cache_valid = false, cache_has_list = false;   // primary hits stored / work list stored with them
+    rtmi_frame_data cache_key{};
+    uint64_t scene_generation = 0, cache_generation = 0;
     unsigned long long *counters = nullptr;
 
     // scene
@@ -466,35 +466,28 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         key.frame_index = 0;
         const bool same_as_stored = c->cache_valid && c->cache_generation == c->scene_generation &&
                                     memcmp(&key, &c->cache_key, sizeof key) == 0;
-        const bool same_as_last = c->last_key_set && c->last_generation == c->scene_generation &&
-                                  memcmp(&key, &c->last_key, sizeof key) == 0;
-        c->last_key = key;
-        c->last_generation = c->scene_generation;
-        c->last_key_set = true;
         // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
         // 12 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
-        // 0.59; 2 paths: 0.23 against 0.20); below 8 the gain is within the scene-to-scene spread.
-        const bool store_pays = c->bvh_active || paths_per_pixel >= 8;
-        if (compact_runs && !c->validate && same_as_stored && store_pays) {
-            variant = RTMI_VARIANT_COMPACT;
-            cache = RT_CACHE_LOAD;
-        } else if (c->bvh_active || paths_per_pixel >= 12 || (compact_runs && !c->validate && same_as_last && store_pays)) {
-            // a camera that has stood still for two launches in a row is worth classifying once
-            variant = RTMI_VARIANT_COMPACT;
-            if (compact_runs && !c->validate) {
-                const size_t np = n_pixels(c);
-                if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
-                if (!c->primary_mat) HIP_TRY(c, hipMalloc(&c->primary_mat, np * sizeof(uint32_t)));
-                cache = RT_CACHE_STORE;
-                c->cache_key = key;
-                c->cache_generation = c->scene_generation;
-            }
-        } else {
-            variant = RTMI_VARIANT_REGENERATE;
+        // 0.59; 2 paths: 0.23 against 0.20); below 8 the one-lane-per-pixel kernel starts from them.
+        const bool use_store = compact_runs && !c->validate;
+        const bool compact = c->bvh_active || paths_per_pixel >= (use_store ? 8u : 12u);
+        if (use_store) {
+            const size_t np = n_pixels(c);
+            if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
+            if (!c->primary_mat) HIP_TRY(c, hipMalloc(&c->primary_mat, np * sizeof(uint32_t)));
+            // the work list is only needed (and only built) by COMPACT
+            cache = (same_as_stored && (!compact || c->cache_has_list)) ? RT_CACHE_LOAD : RT_CACHE_STORE;
+        }
+        variant = compact ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
+        if (cache == RT_CACHE_STORE) {
+            c->cache_key = key;
+            c->cache_generation = c->scene_generation;
+            c->cache_valid = true;
+            c->cache_has_list = compact;
         }
     }
     // any other launch of the classifying kernel rebuilds the work list for its own camera
-    if (variant == RTMI_VARIANT_COMPACT && cache != RT_CACHE_LOAD) c->cache_valid = (cache == RT_CACHE_STORE);
+    if (variant == RTMI_VARIANT_COMPACT && cache == RT_CACHE_NONE) c->cache_has_list = false;
     p.primary = c->primary;
     p.primary_mat = c->primary_mat;
     hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;

@@ -24,7 +24,7 @@ def test_store_use_and_invalidation(rtmi):
     with auto, plain:
         for r in (auto, plain):
             r.upload_scene(ref)
-        fd = rtmi.make_frame_data(w, h, ref, rtmi.BENCH_POSE, rays_per_pixel=8, max_bounce=6)
+        fd = rtmi.make_frame_data(w, h, ref, rtmi.BENCH_POSE, rays_per_pixel=2, max_bounce=6)
         frame = 0
 
         def step(n=1, **change):
@@ -39,13 +39,13 @@ def test_store_use_and_invalidation(rtmi):
         for _ in range(5):
             step()                                  # plain launch, storing launch, three launches from the store
         step(3)                                     # more frames in one launch, still from the store
-        step(rays_per_pixel=9)                      # a frame constant changed: the store is stale
+        step(rays_per_pixel=3)                      # a frame constant changed: the store is stale
         step()
         step()
         step(sun_focus=100.0)                       # sky constants are part of what is stored
         step()
         step()
-        fd2 = rtmi.make_frame_data(w, h, ref, ((0.5, 1.2, -4.0), 80.0, -10.0), rays_per_pixel=9, max_bounce=6)
+        fd2 = rtmi.make_frame_data(w, h, ref, ((0.5, 1.2, -4.0), 80.0, -10.0), rays_per_pixel=3, max_bounce=6)
         fd2.sun_focus = 100.0
         fd = fd2
         frame = 0                                   # the camera moved: the sum starts again
@@ -61,7 +61,7 @@ def test_store_use_and_invalidation(rtmi):
         step(2)
         # an explicit variant-2 launch rebuilds the work list; the next default launch must not trust the store
         auto.set_variant(rtmi.abi.VARIANT_COMPACT)
-        fd3 = rtmi.make_frame_data(w, h, sph, rtmi.DEFAULT_POSE, rays_per_pixel=9, max_bounce=6)
+        fd3 = rtmi.make_frame_data(w, h, sph, rtmi.DEFAULT_POSE, rays_per_pixel=3, max_bounce=6)
         auto.render_frames(fd3, 1, 1)
         plain.render_frames(fd3, 1, 1)
         auto.set_variant(rtmi.abi.VARIANT_AUTO)
