@@ -268,7 +268,7 @@ def test_external_buffer_and_stream(rtmi):
     assert cases.bits_equal(got, want["accum"]) and np.array_equal(out, want["rgba8"])
 
 
-# ---- BASELINE sizes: 1920x1080, depth 8 -----------------------------------------------------------
+# ---- Benchmark sizes: 1920x1080, depth 8 -----------------------------------------------------------
 
 FULL = dict(size=(1920, 1080), rpp=1, max_bounce=8, first=1)
 
@@ -300,7 +300,7 @@ def test_full_size_rows_against_oracle(rtmi, oracle, scene):
 
 
 def test_full_size_split_invariance_256_frames(rtmi):
-    """BASELINE config (1080p, 256 frames, depth 8): one launch == four launches of 64 frames ==
+    """Benchmark configuration (1080p, 256 frames, depth 8): one launch == four launches of 64 frames ==
     the other variant, bit for bit; a second run reproduces the first."""
     case = dict(FULL, scene="spheres", pose=cases.BENCH_POSE)
     sc = cases.product_scene(case)
