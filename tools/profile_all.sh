@@ -1,11 +1,11 @@
 #!/bin/bash
-# One profiling pass for the round's evidence: kernel-trace statistics of the bench command, PMC passes
+# One profiling pass for the committed evidence: kernel-trace statistics of the bench command, PMC passes
 # (each in a run of its own) for the default workload and for the stress workload.
-# usage (on the GPU box): bash tools/profile_round.sh
+# usage (on the GPU box): bash tools/profile_all.sh
 set -e
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-OUT=gpurun_out/round
+OUT=gpurun_out/profile
 mkdir -p $OUT
 # 1. the bench command itself under the kernel trace
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/ks_bench -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/bench_under_trace.err
