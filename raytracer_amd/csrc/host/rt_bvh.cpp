@@ -35,6 +35,12 @@ struct Box {
     }
 };
 
+inline int BinOf(float c, float lo, float scale)
+{
+    const int q = (int)((c - lo) * scale);
+    return q < 0 ? 0 : (q >= kBins ? kBins - 1 : q);
+}
+
 // levels a balanced tree needs for n primitives
 int BalancedDepth(uint32_t n)
 {
@@ -103,26 +109,19 @@ struct Builder {
                 const float *c = &cen[3 * (size_t)order[k]];
                 cb.Grow(c, c);
             }
-            int axis = 0;
-            float ext = -1.0f;
-            for (int a = 0; a < 3; a++) {
-                const float x = cb.hi[a] - cb.lo[a];
-                if (std::isfinite(x) && x > ext) {
-                    ext = x;
-                    axis = a;
-                }
-            }
-            if (ext > 0.0f) {
+            // the cheapest of the 3 x (kBins - 1) candidate planes: (surface area x count) summed over both sides
+            double best = DBL_MAX;
+            int best_axis = -1, best_q = -1;
+            float best_lo = 0.0f, best_scale = 0.0f;
+            for (int axis = 0; axis < 3; axis++) {
+                const float ext = cb.hi[axis] - cb.lo[axis];
+                if (!(std::isfinite(ext) && ext > 0.0f)) continue;
                 const float scale = (float)kBins / ext, lo = cb.lo[axis];
-                auto bin_of = [&](uint32_t id) {
-                    int q = (int)((cen[3 * (size_t)id + axis] - lo) * scale);
-                    return q < 0 ? 0 : (q >= kBins ? kBins - 1 : q);
-                };
                 Box bin_box[kBins];
                 uint32_t bin_n[kBins] = {};
                 for (uint32_t k = b; k < e; k++) {
                     const uint32_t id = order[k];
-                    const int q = bin_of(id);
+                    const int q = BinOf(cen[3 * (size_t)id + axis], lo, scale);
                     bin_n[q]++;
                     bin_box[q].Grow(boxes[id].lo, boxes[id].hi);
                 }
@@ -134,8 +133,6 @@ struct Builder {
                 }
                 Box left;
                 uint32_t left_n = 0;
-                double best = DBL_MAX;
-                int best_q = -1;
                 for (int q = 0; q + 1 < kBins; q++) {
                     left.Grow(bin_box[q]);
                     left_n += bin_n[q];
@@ -146,14 +143,17 @@ struct Builder {
                     const double cost = left.HalfArea() * left_n + right_area[q + 1] * right_n;
                     if (cost < best) {
                         best = cost;
+                        best_axis = axis;
                         best_q = q;
+                        best_lo = lo;
+                        best_scale = scale;
                     }
                 }
-                if (best_q >= 0) {
-                    mid = Partition(b, e, [&](uint32_t id) { return bin_of(id) <= best_q; });
-                    split_found = mid > b && mid < e;
-                    if (!split_found) mid = b + n / 2;
-                }
+            }
+            if (best_axis >= 0) {
+                mid = Partition(b, e, [&](uint32_t id) { return BinOf(cen[3 * (size_t)id + best_axis], best_lo, best_scale) <= best_q; });
+                split_found = mid > b && mid < e;
+                if (!split_found) mid = b + n / 2;
             }
         }
         (void)split_found;  // without one the range is halved in its current order

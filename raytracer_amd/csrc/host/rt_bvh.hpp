@@ -34,8 +34,8 @@ struct PrimBox {
     float margin_floor = 0.0f;
 };
 
-// Builds a hierarchy over boxes[0..n) top-down: each range is split where a 16-bin sweep along the
-// widest axis of its centroids finds the smallest (surface area x count) sum, as long as both sides
+// Builds a hierarchy over boxes[0..n) top-down: each range is split where 16-bin sweeps along the
+// three axes of its centroids find the smallest (surface area x count) sum, as long as both sides
 // can still be finished within kMaxDepth levels; otherwise (and when all centroids coincide) the
 // range is halved.  Leaves hold at most kLeafSize primitives.  Appends inner nodes to `nodes`,
 // returns the root reference, and fills order[k] = index of the primitive at leaf position k
