@@ -38,35 +38,13 @@ constexpr float kBvhSphereKappa = 1.4e-6f;             // > 19 * 2^-24
 constexpr float kBvhTriangleKappa = 5.9604644775e-8f;  // 2^-24: margin 2^-12 |ao|
 constexpr float kBvhTSlack = 1.0078125f;               // 1 + 2^-7
 
-// Entry distance of the ray into the grown box; false when the ray cannot reach anything inside that
-// could win.  NaN (0 * inf, inf - inf) makes a comparison false, which keeps the box.
-__device__ __forceinline__ bool bvh_box(const float4 lo, const float4 hi, float floor_r, V3 o, V3 inv, float kappa,
-                                        float t_limit, float &t_near)
-{
-    const float lx = lo.x - o.x, hx = hi.x - o.x;
-    const float ly = lo.y - o.y, hy = hi.y - o.y;
-    const float lz = lo.z - o.z, hz = hi.z - o.z;
-    const float mx = fmaxf(fabsf(lx), fabsf(hx)), my = fmaxf(fabsf(ly), fabsf(hy)), mz = fmaxf(fabsf(lz), fabsf(hz));
-    const float d2 = mx * mx + my * my + mz * mz;
-    // the hardware square root is good to 1 ulp; the factor 1 + 2^-20 keeps the result an upper bound
-    const float grown = __builtin_amdgcn_sqrtf(floor_r * floor_r + kappa * d2) * 1.00000095367431640625f;
-    const float e = (grown - floor_r) + 1.9073486328125e-6f * fmaxf(fmaxf(mx, my), mz);
-    const float t1 = (lx - e) * inv.x, t2 = (hx + e) * inv.x;
-    const float t3 = (ly - e) * inv.y, t4 = (hy + e) * inv.y;
-    const float t5 = (lz - e) * inv.z, t6 = (hz + e) * inv.z;
-    const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-    const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    t_near = tmin;
-    return !(tmax < 0.0f) && !(tmin > tmax) && !(tmin > t_limit);
-}
-
 // ClosestHit (Raytracing.comp:338-388) over the hierarchies of the uploaded scene, as a resumable
 // per-lane walk.
 //
 // A lane walks, in the shader's group order, the sphere hierarchy and then the hierarchy of every mesh
-// whose box gate its ray passes.  Each trip() does ONE thing for the lane: test the two child boxes of
+// whose box gate its ray passes.  Each step does ONE thing for the lane: test the two child boxes of
 // an inner node, or test one primitive of a leaf, or move on to the lane's next group.  All state is
-// in the struct (and the lane's stack slots), so a caller may stop after any trip, do other work with
+// in the struct (and the lane's stack slots), so a caller may stop after any step, do other work with
 // the lanes that are done, start new rays in them, and come back: lanes of a wave are then at
 // different places of different hierarchies, for different rays, at the same time.
 struct BvhWalk {
@@ -81,7 +59,6 @@ struct BvhWalk {
     uint32_t flags;
     static constexpr uint32_t kActive = 1u;          // the walk has work left
     static constexpr uint32_t kWalking = 2u;         // ref / leaf_left describe work inside the current group
-    static constexpr uint32_t kSpheresPending = 4u;  // the sphere hierarchy has not been walked yet
     static constexpr uint32_t kInSpheres = 8u;       // the current group is the sphere hierarchy
     static constexpr uint32_t kOwnBest = 16u;        // best is a triangle of the current mesh
     __device__ __forceinline__ bool is(uint32_t f) const { return (flags & f) != 0u; }
@@ -149,151 +126,231 @@ __device__ __forceinline__ void bvh_begin(BvhWalk &w, const DeviceScene &sc, uin
     w.a = dot(d, d);
     w.gate_base = 0u;
     w.gates = bvh_gates<COUNT>(sc, 0u, n_meshes, o, w.inv, cn);
-    w.flags = BvhWalk::kActive | ((n_spheres > 0u && sc.bvh_sphere_root != kBvhEmpty) ? BvhWalk::kSpheresPending : 0u);
     w.cur_mesh = 0u;
-    w.ref = kBvhEmpty;
     w.leaf_pos = 0u;
     w.leaf_left = 0u;
     w.sp = 0;
+    if (n_spheres > 0u && sc.bvh_sphere_root != kBvhEmpty) {
+        // the first group: the sphere hierarchy
+        w.flags = BvhWalk::kActive | BvhWalk::kWalking | BvhWalk::kInSpheres;
+        w.ref = sc.bvh_sphere_root;
+    } else {
+        w.flags = (w.gates != 0ull || n_meshes > 64u) ? BvhWalk::kActive : 0u;
+        w.ref = kBvhEmpty;
+    }
 }
 
-// One step of the lane's walk.  stack points at this lane's first slot; consecutive levels are
-// stride words apart.
+// The lane has finished its current group; the walk is over when no gated mesh is left either.
+__device__ __forceinline__ void bvh_group_done(BvhWalk &w, uint32_t n_meshes)
+{
+    w.clear(BvhWalk::kWalking);
+    if (w.gates == 0ull && n_meshes - w.gate_base <= 64u) w.clear(BvhWalk::kActive);
+}
+
+// true when the next thing the lane's walk needs is an inner node (both child boxes)
+__device__ __forceinline__ bool bvh_at_inner(const BvhWalk &w)
+{
+    return w.is(BvhWalk::kWalking) && w.leaf_left == 0u && (w.ref & kBvhLeafFlag) == 0u;
+}
+
+// One inner node for a lane with bvh_at_inner(): both child boxes, then on to the nearer child that
+// the ray can reach (the other one, if reachable too, goes on the stack).  stack points at this lane's
+// first slot; consecutive levels are stride words apart.
+//
+// Both boxes are grown by ONE margin, computed for their union: D^2 over the union bounds |oc|^2 for
+// everything below either child, and the smaller of the two radius floors gives the larger margin.
+// The margin arithmetic is not part of the shader's arithmetic (it only has to be an upper bound), so
+// it uses fused multiply-adds.
 template <bool COUNT>
-__device__ __forceinline__ void bvh_trip(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
-                                         Counters &cn, uint32_t *stack, uint32_t stride)
+__device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uint32_t n_meshes, V3 o, Counters &cn, uint32_t *stack,
+                                          uint32_t stride)
+{
+    const float4 *__restrict__ rec = sc.bvh_nodes + 4 * (size_t)w.ref;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    if (COUNT) cn.c[3] += 2u;
+    const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
+    const float t_limit = w.best.t * kBvhTSlack;
+    const float l0x = q0.x - o.x, l1x = q1.x - o.x, r0x = q2.x - o.x, r1x = q3.x - o.x;
+    const float l0y = q0.y - o.y, l1y = q1.y - o.y, r0y = q2.y - o.y, r1y = q3.y - o.y;
+    const float l0z = q0.z - o.z, l1z = q1.z - o.z, r0z = q2.z - o.z, r1z = q3.z - o.z;
+    const float mx = fmaxf(fmaxf(fmaxf(fabsf(l0x), fabsf(l1x)), fabsf(r0x)), fabsf(r1x));
+    const float my = fmaxf(fmaxf(fmaxf(fabsf(l0y), fabsf(l1y)), fabsf(r0y)), fabsf(r1y));
+    const float mz = fmaxf(fmaxf(fmaxf(fabsf(l0z), fabsf(l1z)), fabsf(r0z)), fabsf(r1z));
+    const float d2 = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+    const float floor_r = fminf(q2.w, q3.w);
+    // the hardware square root is good to 1 ulp; the factor 1 + 2^-20 keeps the result an upper bound
+    const float grown = __builtin_amdgcn_sqrtf(__builtin_fmaf(kappa, d2, floor_r * floor_r)) * 1.00000095367431640625f;
+    const float e = __builtin_fmaf(1.9073486328125e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r);
+    // Entry and exit distances of the grown boxes.  NaN (0 * inf, inf - inf) makes a comparison false,
+    // which keeps the box.
+    const V3 inv = w.inv;
+    const float a1 = (l0x - e) * inv.x, a2 = (l1x + e) * inv.x;
+    const float a3 = (l0y - e) * inv.y, a4 = (l1y + e) * inv.y;
+    const float a5 = (l0z - e) * inv.z, a6 = (l1z + e) * inv.z;
+    const float b1 = (r0x - e) * inv.x, b2 = (r1x + e) * inv.x;
+    const float b3 = (r0y - e) * inv.y, b4 = (r1y + e) * inv.y;
+    const float b5 = (r0z - e) * inv.z, b6 = (r1z + e) * inv.z;
+    const float tl = fmaxf(fmaxf(fminf(a1, a2), fminf(a3, a4)), fminf(a5, a6));
+    const float tl_far = fminf(fminf(fmaxf(a1, a2), fmaxf(a3, a4)), fmaxf(a5, a6));
+    const float tr = fmaxf(fmaxf(fminf(b1, b2), fminf(b3, b4)), fminf(b5, b6));
+    const float tr_far = fminf(fminf(fmaxf(b1, b2), fmaxf(b3, b4)), fmaxf(b5, b6));
+    const bool hl = !(tl_far < 0.0f) && !(tl > tl_far) && !(tl > t_limit);
+    const bool hr = !(tr_far < 0.0f) && !(tr > tr_far) && !(tr > t_limit);
+    const uint32_t L = __float_as_uint(q0.w), R = __float_as_uint(q1.w);
+    if (hl && hr) {
+        const bool right_first = tr < tl;
+        stack[(uint32_t)w.sp * stride] = right_first ? L : R;  // sp < kBvhStack: one entry per level
+        w.sp++;
+        w.ref = right_first ? R : L;
+    } else if (hl) {
+        w.ref = L;
+    } else if (hr) {
+        w.ref = R;
+    } else if (w.sp == 0) {
+        bvh_group_done(w, n_meshes);
+    } else {
+        w.ref = stack[(uint32_t)(--w.sp) * stride];
+    }
+}
+
+// RaySphere (Raytracing.comp:130-161) for leaf entry e, whose record is g = {centre, r^2}
+template <bool COUNT>
+__device__ __forceinline__ void bvh_sphere(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, V3 o, V3 d, float4 g, size_t e,
+                                           Counters &cn)
+{
+    const V3 oc = o - mk(g.x, g.y, g.z);
+    const float b = 2.0f * dot(oc, d);
+    const float c = dot(oc, oc) - g.w;
+    const float disc = b * b - (4.0f * w.a) * c;
+    if (disc >= 0.0f) {
+        const float t = (-b - sqrtf(disc)) / (2.0f * w.a);
+        if (t > 0.0001f && t <= w.best.t) {
+            // the shader's loop keeps the lowest index among equal t
+            const uint32_t id = sc.bvh_sphere_id[e];
+            if (id < n_spheres && (t < w.best.t || (id < w.best.prim && w.best.prim != kMissId))) {
+                w.best.t = t;
+                w.best.prim = id;
+                w.best.mat = id;
+            }
+        }
+    }
+    if (COUNT) {
+        // spheres beyond the count this frame names are not tests the shader makes
+        if (sc.bvh_sphere_id[e] < n_spheres) {
+            cn.c[0]++;
+            if (disc >= 0.0f) cn.c[1]++;
+        }
+    }
+}
+
+// One step for a lane that is not at an inner node: the lane's next group (the spheres first, then the
+// gated meshes in index order), or the next primitive(s) of the leaf it is in.
+template <bool COUNT>
+__device__ __forceinline__ void bvh_other(BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o, V3 d,
+                                          Counters &cn, uint32_t *stack, uint32_t stride)
 {
     if (!w.is(BvhWalk::kWalking)) {
-        // next group of this lane: the spheres first, then the gated meshes in index order
-        if (w.is(BvhWalk::kSpheresPending)) {
-            w.clear(BvhWalk::kSpheresPending);
-            w.set(BvhWalk::kInSpheres);
-            w.ref = sc.bvh_sphere_root;
-        } else if (w.gates != 0ull) {
+        if (w.gates != 0ull) {
             const uint32_t b = (uint32_t)__ffsll((long long)w.gates) - 1u;
             w.gates &= w.gates - 1ull;
             w.cur_mesh = w.gate_base + b;
             w.clear(BvhWalk::kInSpheres | BvhWalk::kOwnBest);
             w.ref = sc.bvh_mesh_root[w.cur_mesh];
-            if (w.ref == kBvhEmpty) return;
+            if (w.ref == kBvhEmpty) {
+                bvh_group_done(w, n_meshes);
+                return;
+            }
+            w.set(BvhWalk::kWalking);
+            w.leaf_left = 0u;
+            w.sp = 0;
         } else if (n_meshes - w.gate_base > 64u) {
             w.gate_base += 64u;
             w.gates = bvh_gates<COUNT>(sc, w.gate_base, n_meshes, o, w.inv, cn);
-            return;
+            if (w.gates == 0ull && n_meshes - w.gate_base <= 64u) w.clear(BvhWalk::kActive);
         } else {
             w.clear(BvhWalk::kActive);
-            return;
         }
-        w.set(BvhWalk::kWalking);
-        w.leaf_left = 0u;
-        w.sp = 0;
+        return;
     }
 
-    if (w.leaf_left == 0u && (w.ref & kBvhLeafFlag)) {
+    if (w.leaf_left == 0u) {
+        // bvh_at_inner() is false, so ref names a leaf
         w.leaf_pos = w.ref & 0x0FFFFFFFu;
         w.leaf_left = (w.ref >> 28) & 7u;
     }
-    // One fetch for whatever the lane does on this trip, issued before the lanes part ways: an inner
-    // node (4 x 16 bytes), a triangle's intersection record (4 x 16 bytes) or a sphere (16 bytes, read
-    // four times).  A wave whose lanes are in different modes then waits for memory once per trip,
-    // not once per mode.
-    const bool in_leaf = w.leaf_left != 0u;
-    const bool sphere_leaf = in_leaf && w.is(BvhWalk::kInSpheres);
     const size_t e = w.leaf_pos;
-    const float4 *__restrict__ rec = in_leaf ? (sphere_leaf ? sc.bvh_sphere_geom + e : sc.bvh_tri_isect + 4 * e)
-                                             : sc.bvh_nodes + 4 * (size_t)w.ref;
-    const uint32_t step = sphere_leaf ? 0u : 1u;
-    const float4 q0 = rec[0];
-    const float4 q1 = rec[step];
-    const float4 q2 = rec[2u * step];
-    const float4 q3 = rec[3u * step];
-
-    if (in_leaf) {
-        // ---- one primitive of a leaf
+    if (w.is(BvhWalk::kInSpheres)) {
+        // up to two spheres of the leaf per step, fetched together
+        const bool two = w.leaf_left >= 2u;
+        const size_t e1 = two ? e + 1u : e;
+        const float4 g0 = sc.bvh_sphere_geom[e];
+        const float4 g1 = sc.bvh_sphere_geom[e1];
+        bvh_sphere<COUNT>(w, sc, n_spheres, o, d, g0, e, cn);
+        if (two) bvh_sphere<COUNT>(w, sc, n_spheres, o, d, g1, e1, cn);
+        const uint32_t took = two ? 2u : 1u;
+        w.leaf_pos += took;
+        w.leaf_left -= took;
+    } else {
+        // RayTriangle, Raytracing.comp:286-309
         w.leaf_pos++;
         w.leaf_left--;
-        if (sphere_leaf) {
-            // RaySphere, Raytracing.comp:130-161
-            const float4 g = q0;
-            const V3 oc = o - mk(g.x, g.y, g.z);
-            const float b = 2.0f * dot(oc, d);
-            const float c = dot(oc, oc) - g.w;
-            const float disc = b * b - (4.0f * w.a) * c;
-            if (disc >= 0.0f) {
-                const float t = (-b - sqrtf(disc)) / (2.0f * w.a);
-                if (t > 0.0001f && t <= w.best.t) {
-                    // the shader's loop keeps the lowest index among equal t
-                    const uint32_t id = sc.bvh_sphere_id[e];
-                    if (id < n_spheres && (t < w.best.t || (id < w.best.prim && w.best.prim != kMissId))) {
-                        w.best.t = t;
-                        w.best.prim = id;
-                        w.best.mat = id;
-                    }
-                }
-            }
-            if (COUNT) {
-                // spheres beyond the count this frame names are not tests the shader makes
-                if (sc.bvh_sphere_id[e] < n_spheres) {
-                    cn.c[0]++;
-                    if (disc >= 0.0f) cn.c[1]++;
-                }
-            }
-        } else {
-            // RayTriangle, Raytracing.comp:286-309
-            const float4 P = q0, AB = q1, AC = q2, N = q3;
-            if (COUNT) cn.c[4]++;
-            const V3 nrm = mk(N.x, N.y, N.z);
-            const float det = -dot(d, nrm);
-            if (det >= 1e-6f) {
-                const V3 ao = o - mk(P.x, P.y, P.z);
-                const V3 dao = cross(ao, d);
-                const float inv_det = 1.0f / det;
-                const float t = dot(ao, nrm) * inv_det;
-                const float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv_det;
-                const float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv_det;
-                const float wgt = 1.0f - u - v;
-                if (t >= 0.0f && u >= 0.0f && v >= 0.0f && wgt >= 0.0f && t <= w.best.t) {
-                    // a triangle of this mesh replaces an equal-t winner only if that winner is a
-                    // higher-indexed triangle of this same mesh: earlier groups keep their ties
-                    const uint32_t prim = n_spheres + sc.bvh_tri_id[e];
-                    if (t < w.best.t || (w.is(BvhWalk::kOwnBest) && prim < w.best.prim)) {
-                        w.best.t = t;
-                        w.best.prim = prim;
-                        w.best.mat = sc.n_spheres + w.cur_mesh;
-                        w.best.u = u;
-                        w.best.v = v;
-                        w.set(BvhWalk::kOwnBest);
-                    }
+        const float4 *__restrict__ rec = sc.bvh_tri_isect + 4 * e;
+        const float4 P = rec[0], AB = rec[1], AC = rec[2], N = rec[3];
+        if (COUNT) cn.c[4]++;
+        const V3 nrm = mk(N.x, N.y, N.z);
+        const float det = -dot(d, nrm);
+        if (det >= 1e-6f) {
+            const V3 ao = o - mk(P.x, P.y, P.z);
+            const V3 dao = cross(ao, d);
+            const float inv_det = 1.0f / det;
+            const float t = dot(ao, nrm) * inv_det;
+            const float u = dot(mk(AC.x, AC.y, AC.z), dao) * inv_det;
+            const float v = -dot(mk(AB.x, AB.y, AB.z), dao) * inv_det;
+            const float wgt = 1.0f - u - v;
+            if (t >= 0.0f && u >= 0.0f && v >= 0.0f && wgt >= 0.0f && t <= w.best.t) {
+                // a triangle of this mesh replaces an equal-t winner only if that winner is a
+                // higher-indexed triangle of this same mesh: earlier groups keep their ties
+                const uint32_t prim = n_spheres + sc.bvh_tri_id[e];
+                if (t < w.best.t || (w.is(BvhWalk::kOwnBest) && prim < w.best.prim)) {
+                    w.best.t = t;
+                    w.best.prim = prim;
+                    w.best.mat = sc.n_spheres + w.cur_mesh;
+                    w.best.u = u;
+                    w.best.v = v;
+                    w.set(BvhWalk::kOwnBest);
                 }
             }
         }
-        if (w.leaf_left == 0u) {
-            if (w.sp == 0) w.clear(BvhWalk::kWalking);
-            else w.ref = stack[(uint32_t)(--w.sp) * stride];
-        }
+    }
+    if (w.leaf_left == 0u) {
+        if (w.sp == 0) bvh_group_done(w, n_meshes);
+        else w.ref = stack[(uint32_t)(--w.sp) * stride];
+    }
+}
+
+// the lanes that are not at an inner node wait while they are fewer than NUM / DEN of those that are
+#ifndef RT_BVH_WAIT_NUM
+#define RT_BVH_WAIT_NUM 3
+#define RT_BVH_WAIT_DEN 4
+#endif
+
+// One pass of the wave over its walks; every lane of the wave that is in the enclosing control flow
+// must call it, stepping or not.  The three kinds of step (inner node, sphere of a leaf, triangle of a
+// leaf or change of group) are different code, and a wave whose lanes want different kinds would run
+// all of it for every pass, most lanes idle in each part.  So a pass runs ONE kind: inner nodes while
+// enough lanes are at one, otherwise everything else for the lanes that have been waiting.
+template <bool COUNT>
+__device__ __forceinline__ void bvh_pass(bool stepping, BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o,
+                                         V3 d, Counters &cn, uint32_t *stack, uint32_t stride)
+{
+    const bool inner = stepping && bvh_at_inner(w);
+    const bool other = stepping && !inner;
+    const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+    const uint32_t n_other = (uint32_t)__popcll(__ballot(other));
+    if (n_inner != 0u && n_other * RT_BVH_WAIT_DEN < n_inner * RT_BVH_WAIT_NUM) {
+        if (inner) bvh_inner<COUNT>(w, sc, n_meshes, o, cn, stack, stride);
     } else {
-        // ---- one inner node: both child boxes
-        if (COUNT) cn.c[3] += 2u;
-        const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
-        const float t_limit = w.best.t * kBvhTSlack;
-        float tl, tr;
-        const bool hl = bvh_box(q0, q1, q2.w, o, w.inv, kappa, t_limit, tl);
-        const bool hr = bvh_box(q2, q3, q3.w, o, w.inv, kappa, t_limit, tr);
-        const uint32_t L = __float_as_uint(q0.w), R = __float_as_uint(q1.w);
-        if (hl && hr) {
-            const bool right_first = tr < tl;
-            stack[(uint32_t)w.sp * stride] = right_first ? L : R;  // sp < kBvhStack: one entry per level
-            w.sp++;
-            w.ref = right_first ? R : L;
-        } else if (hl) {
-            w.ref = L;
-        } else if (hr) {
-            w.ref = R;
-        } else if (w.sp == 0) {
-            w.clear(BvhWalk::kWalking);
-        } else {
-            w.ref = stack[(uint32_t)(--w.sp) * stride];
-        }
+        if (other) bvh_other<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
     }
 }
 
@@ -304,7 +361,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const DeviceScene &sc, uint32_t n
 {
     BvhWalk w;
     bvh_begin<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn);
-    while (w.active()) bvh_trip<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
+    while (__ballot(w.active()) != 0ull) bvh_pass<COUNT>(w.active(), w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
     return w.best;
 }
 
