@@ -5,12 +5,18 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <exception>
 #include <numeric>
+#include <thread>
 
 namespace rtmi {
 namespace {
 
 constexpr int kBins = 16;
+// The two halves of a range are built side by side on two threads for the first kForkLevels levels,
+// as long as a half holds at least kForkMin primitives.
+constexpr int kForkLevels = 4;
+constexpr uint32_t kForkMin = 16384;
 
 struct Box {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
@@ -52,13 +58,18 @@ int BalancedDepth(uint32_t n)
     return d;
 }
 
+// A primitive as the builder moves it around: the passes over a range then read memory in order.
+struct Item {
+    float lo[3], hi[3];
+    float cen[3];        // centroid (NaN replaced by 0)
+    float margin_floor;  // NaN and negative values replaced by 0
+    uint32_t id;
+};
+
 struct Builder {
-    const std::vector<PrimBox> &boxes;
-    std::vector<uint32_t> &order;
-    std::vector<BvhNode> &nodes;
+    std::vector<Item> items;  // in leaf order when the build is done
+    std::vector<Item> tmp;    // partition scratch: a range [b, e) of items uses tmp[b, e)
     uint32_t leaf_base;
-    std::vector<float> cen;       // centroids, 3 per primitive (NaN replaced by 0)
-    std::vector<uint32_t> tmp;    // partition scratch
 
     struct Result {
         uint32_t ref;
@@ -71,71 +82,76 @@ struct Builder {
         Result r;
         r.margin_floor = FLT_MAX;
         for (uint32_t k = b; k < e; k++) {
-            const PrimBox &p = boxes[order[k]];
+            const Item &p = items[k];
             r.box.Grow(p.lo, p.hi);
-            const float f = p.margin_floor >= 0.0f ? p.margin_floor : 0.0f;  // NaN -> 0
-            if (f < r.margin_floor) r.margin_floor = f;
+            if (p.margin_floor < r.margin_floor) r.margin_floor = p.margin_floor;
         }
         r.ref = kLeafFlag | ((e - b) << 28) | (leaf_base + b);
         return r;
     }
 
-    // Stable split of order[b, e) by pred; returns the first index of the second part.
+    // Stable split of items[b, e) by pred; returns the first index of the second part.
     template <class Pred>
     uint32_t Partition(uint32_t b, uint32_t e, Pred pred)
     {
-        uint32_t w = b, t = 0;
+        uint32_t w = b, t = b;
         for (uint32_t k = b; k < e; k++) {
-            const uint32_t id = order[k];
-            if (pred(id)) order[w++] = id;
-            else tmp[t++] = id;
+            if (pred(items[k])) items[w++] = items[k];
+            else tmp[t++] = items[k];
         }
-        std::copy(tmp.begin(), tmp.begin() + t, order.begin() + w);
+        std::copy(tmp.begin() + b, tmp.begin() + t, items.begin() + w);
         return w;
     }
 
-    // Builds order[b, e) with at most `levels` further levels of inner nodes.
-    Result Range(uint32_t b, uint32_t e, int levels)
+    // Builds items[b, e) with at most `levels` further levels of inner nodes, appending its nodes to
+    // `nodes` in pre-order; references are indices into `nodes`.  `fork` levels of the recursion may
+    // still split their work over two threads; the result does not depend on it.
+    Result Range(uint32_t b, uint32_t e, int levels, std::vector<BvhNode> &nodes, int fork)
     {
         const uint32_t n = e - b;
         if (n <= kLeafSize) return Leaf(b, e);
 
         uint32_t mid = b + n / 2;
-        bool split_found = false;
         // a free split is allowed while a balanced finish of the larger side still fits afterwards
         if (levels > BalancedDepth(n)) {
             Box cb;
-            for (uint32_t k = b; k < e; k++) {
-                const float *c = &cen[3 * (size_t)order[k]];
-                cb.Grow(c, c);
-            }
+            for (uint32_t k = b; k < e; k++) cb.Grow(items[k].cen, items[k].cen);
             // the cheapest of the 3 x (kBins - 1) candidate planes: (surface area x count) summed over both sides
             double best = DBL_MAX;
             int best_axis = -1, best_q = -1;
             float best_lo = 0.0f, best_scale = 0.0f;
+            Box bin_box[3][kBins];
+            uint32_t bin_n[3][kBins] = {};
+            float lo[3], scale[3];
+            bool usable[3];
             for (int axis = 0; axis < 3; axis++) {
                 const float ext = cb.hi[axis] - cb.lo[axis];
-                if (!(std::isfinite(ext) && ext > 0.0f)) continue;
-                const float scale = (float)kBins / ext, lo = cb.lo[axis];
-                Box bin_box[kBins];
-                uint32_t bin_n[kBins] = {};
-                for (uint32_t k = b; k < e; k++) {
-                    const uint32_t id = order[k];
-                    const int q = BinOf(cen[3 * (size_t)id + axis], lo, scale);
-                    bin_n[q]++;
-                    bin_box[q].Grow(boxes[id].lo, boxes[id].hi);
+                usable[axis] = std::isfinite(ext) && ext > 0.0f;
+                scale[axis] = usable[axis] ? (float)kBins / ext : 0.0f;
+                lo[axis] = cb.lo[axis];
+            }
+            for (uint32_t k = b; k < e; k++) {
+                const Item &p = items[k];
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!usable[axis]) continue;
+                    const int q = BinOf(p.cen[axis], lo[axis], scale[axis]);
+                    bin_n[axis][q]++;
+                    bin_box[axis][q].Grow(p.lo, p.hi);
                 }
+            }
+            for (int axis = 0; axis < 3; axis++) {
+                if (!usable[axis]) continue;
                 double right_area[kBins];
                 Box acc;
                 for (int q = kBins - 1; q > 0; q--) {
-                    acc.Grow(bin_box[q]);
+                    acc.Grow(bin_box[axis][q]);
                     right_area[q] = acc.HalfArea();
                 }
                 Box left;
                 uint32_t left_n = 0;
                 for (int q = 0; q + 1 < kBins; q++) {
-                    left.Grow(bin_box[q]);
-                    left_n += bin_n[q];
+                    left.Grow(bin_box[axis][q]);
+                    left_n += bin_n[axis][q];
                     const uint32_t right_n = n - left_n;
                     if (left_n == 0 || right_n == 0) continue;
                     // the larger side must still fit into the remaining levels
@@ -145,23 +161,53 @@ struct Builder {
                         best = cost;
                         best_axis = axis;
                         best_q = q;
-                        best_lo = lo;
-                        best_scale = scale;
+                        best_lo = lo[axis];
+                        best_scale = scale[axis];
                     }
                 }
             }
             if (best_axis >= 0) {
-                mid = Partition(b, e, [&](uint32_t id) { return BinOf(cen[3 * (size_t)id + best_axis], best_lo, best_scale) <= best_q; });
-                split_found = mid > b && mid < e;
-                if (!split_found) mid = b + n / 2;
+                mid = Partition(b, e, [&](const Item &p) { return BinOf(p.cen[best_axis], best_lo, best_scale) <= best_q; });
+                if (mid == b || mid == e) mid = b + n / 2;  // cannot happen for a split with both counts > 0
             }
         }
-        (void)split_found;  // without one the range is halved in its current order
+        // without a split the range is halved in its current order
 
         const uint32_t self = (uint32_t)nodes.size();
         nodes.emplace_back();
-        const Result l = Range(b, mid, levels - 1);
-        const Result r = Range(mid, e, levels - 1);
+        Result l, r;
+        if (fork > 0 && mid - b >= kForkMin && e - mid >= kForkMin) {
+            // the right half on a thread of its own, into a vector of its own that is appended (with
+            // its references moved) behind the left half's nodes
+            std::vector<BvhNode> right_nodes;
+            right_nodes.reserve(e - mid);  // more than it can need; reserved here so that the worker never allocates
+            std::exception_ptr failure;
+            std::thread worker([&] {
+                try {
+                    r = Range(mid, e, levels - 1, right_nodes, fork - 1);
+                } catch (...) {
+                    failure = std::current_exception();
+                }
+            });
+            try {
+                l = Range(b, mid, levels - 1, nodes, fork - 1);
+            } catch (...) {
+                worker.join();
+                throw;
+            }
+            worker.join();
+            if (failure) std::rethrow_exception(failure);
+            const uint32_t shift = (uint32_t)nodes.size();
+            for (BvhNode &nd : right_nodes) {
+                if (!(nd.left & kLeafFlag)) nd.left += shift;
+                if (!(nd.right & kLeafFlag)) nd.right += shift;
+            }
+            if (!(r.ref & kLeafFlag)) r.ref += shift;
+            nodes.insert(nodes.end(), right_nodes.begin(), right_nodes.end());
+        } else {
+            l = Range(b, mid, levels - 1, nodes, 0);
+            r = Range(mid, e, levels - 1, nodes, 0);
+        }
         BvhNode &nd = nodes[self];
         for (int a = 0; a < 3; a++) {
             nd.l_lo[a] = l.box.lo[a];
@@ -201,19 +247,24 @@ uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes
     const uint32_t n = (uint32_t)boxes.size();
     order.resize(n);
     if (n == 0) return kEmptyRef;
-    std::iota(order.begin(), order.end(), 0u);
 
-    Builder bld{boxes, order, nodes, leaf_base, {}, {}};
-    bld.cen.resize(3 * (size_t)n);
-    bld.tmp.resize(n);
+    Builder bld;
+    bld.leaf_base = leaf_base;
+    std::vector<Item> unsorted(n);
     Box cb;
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t i = 0; i < n; i++) {
+        Item &it = unsorted[i];
         for (int a = 0; a < 3; a++) {
+            it.lo[a] = boxes[i].lo[a];
+            it.hi[a] = boxes[i].hi[a];
             float m = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
             if (!std::isfinite(m)) m = 0.0f;
-            bld.cen[3 * (size_t)i + a] = m;
+            it.cen[a] = m;
         }
-    for (uint32_t i = 0; i < n; i++) cb.Grow(&bld.cen[3 * (size_t)i], &bld.cen[3 * (size_t)i]);
+        it.margin_floor = boxes[i].margin_floor >= 0.0f ? boxes[i].margin_floor : 0.0f;  // NaN -> 0
+        it.id = i;
+        cb.Grow(it.cen, it.cen);
+    }
 
     // Start from a Morton order (ties by index): ranges that end up halved without a surface-area
     // split (all centroids equal, or the depth limit reached) are then still spatially coherent.
@@ -226,17 +277,25 @@ uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes
     for (uint32_t i = 0; i < n; i++) {
         uint32_t q[3];
         for (int a = 0; a < 3; a++) {
-            float f = (bld.cen[3 * (size_t)i + a] - cb.lo[a]) * scale[a];
+            float f = (unsorted[i].cen[a] - cb.lo[a]) * scale[a];
             if (!(f >= 0.0f)) f = 0.0f;
             if (f > 1023.0f) f = 1023.0f;
             q[a] = (uint32_t)f;
         }
         code[i] = (Spread10(q[0]) << 2) | (Spread10(q[1]) << 1) | Spread10(q[2]);
     }
+    std::iota(order.begin(), order.end(), 0u);
     std::sort(order.begin(), order.end(),
               [&](uint32_t x, uint32_t y) { return code[x] != code[y] ? code[x] < code[y] : x < y; });
+    bld.items.resize(n);
+    for (uint32_t k = 0; k < n; k++) bld.items[k] = unsorted[order[k]];
+    std::vector<Item>().swap(unsorted);
+    bld.tmp.resize(n);
 
-    return bld.Range(0, n, kMaxDepth).ref;
+    nodes.reserve(nodes.size() + n);
+    const uint32_t root = bld.Range(0, n, kMaxDepth, nodes, kForkLevels).ref;
+    for (uint32_t k = 0; k < n; k++) order[k] = bld.items[k].id;
+    return root;
 }
 
 }  // namespace rtmi

@@ -41,6 +41,8 @@ struct PrimBox {
 // returns the root reference, and fills order[k] = index of the primitive at leaf position k
 // (order is local to this call: 0..n-1).  Leaf references count from leaf_base, so that several
 // hierarchies can share one leaf-ordered primitive array (n at most kMaxPrimitives, leaf_base + n below 2^28).
+// Large ranges are split over several threads; the nodes come out in pre-order with the same bytes as
+// a single-threaded build would give.
 uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes, std::vector<uint32_t> &order,
                   uint32_t leaf_base);
 

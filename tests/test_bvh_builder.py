@@ -40,7 +40,8 @@ def walk(nodes, order, boxes, ref, leaf_base, seen, depth=1):
     return np.minimum(out[0][0], out[1][0]), np.maximum(out[0][1], out[1][1]), max(out[0][2], out[1][2])
 
 
-@pytest.mark.parametrize("n", [1, 2, 4, 5, 9, 1000, 4097])
+# 70000: large enough for the builder to split the work over several threads
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 9, 1000, 4097, 70000])
 def test_tree_covers_every_box_once(rtmi, n):
     rs = np.random.RandomState(n)
     c = rs.uniform(-10, 10, size=(n, 3))
@@ -53,6 +54,25 @@ def test_tree_covers_every_box_once(rtmi, n):
     _, _, depth = walk(nodes, order, boxes, root, leaf_base, seen)
     assert sorted(seen) == list(range(n))
     assert depth <= 25    # 24 levels of inner nodes and the leaves: what the traversal stack is sized for
+
+
+def test_threads_do_not_change_the_tree(rtmi):
+    """Nodes are numbered in pre-order whichever thread built them: every inner child reference points
+    forward, a left inner child is the next node, and two builds give the same bytes."""
+    rs = np.random.RandomState(5)
+    c = rs.uniform(-10, 10, size=(150000, 3))
+    boxes = np.concatenate([c - 0.05, c + 0.05], axis=1).astype(np.float32)
+    nodes, order, root = build(rtmi, boxes)
+    nodes2, order2, root2 = build(rtmi, boxes)
+    assert root == root2 == 0 and (nodes == nodes2).all() and (order == order2).all()
+    left, right = nodes[:, 3], nodes[:, 7]
+    idx = np.arange(len(nodes), dtype=np.uint32)
+    inner_l, inner_r = (left & LEAF) == 0, (right & LEAF) == 0
+    assert (left[inner_l] == idx[inner_l] + 1).all()
+    assert (right[inner_r] > idx[inner_r]).all() and (right[inner_r] < len(nodes)).all()
+    # every node except the root is referenced exactly once
+    refs = np.concatenate([left[inner_l], right[inner_r]])
+    assert len(refs) == len(nodes) - 1 and len(np.unique(refs)) == len(refs)
 
 
 def test_empty_and_identical_boxes(rtmi):
