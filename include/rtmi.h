@@ -114,7 +114,7 @@ typedef enum rtmi_variant {
  * a bounding volume hierarchy (built on the host at upload: one over the spheres, one per mesh) only
  * the primitives near the ray get the shader's tests.  The hit returned is the same: the tests are
  * the shader's own, the box tests carry margins for their rounding, and ties keep the shader's loop
- * order.  RTMI_ACCEL_AUTO builds hierarchies when the scene holds more than 384 primitives.  The
+ * order.  RTMI_ACCEL_AUTO builds hierarchies when the scene holds more than 256 primitives.  The
  * reference has no counterpart (its scenes hold 5 spheres and 12 triangles, main.cpp:125-164). */
 typedef enum rtmi_accel {
     RTMI_ACCEL_AUTO = 0,

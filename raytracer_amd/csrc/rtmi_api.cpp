@@ -109,7 +109,7 @@ inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 // primitive count above which RTMI_ACCEL_AUTO builds hierarchies
 // (measured on random sphere scenes at 1080p: the hierarchy overtakes the exhaustive loops between 256 and
 // 512 primitives)
-constexpr uint32_t kAutoBvhThreshold = 384;
+constexpr uint32_t kAutoBvhThreshold = 256;
 
 // largest float <= v and smallest float >= v
 inline float round_down(double v)
