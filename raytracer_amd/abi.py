@@ -20,6 +20,7 @@ VARIANT_MEGAKERNEL = 0
 VARIANT_REGENERATE = 1
 VARIANT_COMPACT = 2
 VARIANT_AUTO = 3
+VARIANT_STREAM = 4
 
 ACCEL_AUTO = 0
 ACCEL_NONE = 1

@@ -328,6 +328,13 @@ __device__ __forceinline__ void bvh_other(BvhWalk &w, const DeviceScene &sc, uin
     }
 }
 
+// kernels that resume walks (k_paths, k_stream): the walking lanes of a wave step together until at
+// most NUM / 2^SHIFT of them are still walking
+#ifndef RT_BVH_KEEP_NUM
+#define RT_BVH_KEEP_NUM 1
+#define RT_BVH_KEEP_SHIFT 1
+#endif
+
 // the lanes that are not at an inner node wait while they are fewer than NUM / DEN of those that are
 #ifndef RT_BVH_WAIT_NUM
 #define RT_BVH_WAIT_NUM 3

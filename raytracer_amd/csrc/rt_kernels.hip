@@ -3,7 +3,7 @@
 // registers across all frames of the launch, so the float4 accumulation image is read and written
 // once per launch instead of once per frame.
 //
-// Three variants, all bit-identical in every output:
+// Four variants, all bit-identical in every output:
 //   k_megakernel   loops nested as the shader nests them (frames, samples, bounces);
 //   k_regenerate   the three loops flattened into one loop over segments (a lane that ends a path
 //                  starts its next one at once);
@@ -16,7 +16,9 @@
 //                  compacted pixels and its lanes share all (pixel, frame) work items of those pixels,
 //                  a lane that finishes an item taking the wave's next one, while per-frame results
 //                  pass through a small LDS ring so that every pixel's sum is still formed in frame
-//                  order.
+//                  order;
+//   k_stream       (scenes with a hierarchy) persistent waves whose lanes take pixel after pixel from a
+//                  launch-wide cursor and resume their walks through the hierarchy.
 #include "rt_kernels.hpp"
 
 #include "rt_device.hpp"
@@ -132,22 +134,27 @@ __device__ __forceinline__ Hit scene_hit(const DeviceScene &sc, uint32_t n_spher
 // cn holds events counted one by one; per_path holds the events of one cached primary segment, which
 // the shader would have repeated for each of the pixel's n_paths paths.
 template <bool VALIDATE>
+__device__ __forceinline__ void store_pixel(const RenderParams &p, uint32_t x, uint32_t y, V3 sum, uint32_t first_prim, uint32_t hash,
+                                            uint32_t rng)
+{
+    const size_t px = (size_t)y * p.width + x;
+    p.accum[px] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    const float div = (float)(p.first_frame + p.n_frames - 1u);
+    const uint32_t r = unorm8(sum.x / div), g = unorm8(sum.y / div), b = unorm8(sum.z / div);
+    p.out_rgba8[px] = r | (g << 8) | (b << 16) | 0xFF000000u;
+    if (VALIDATE) {
+        p.hit_ids[px] = first_prim;
+        p.chain_hash[px] = hash;
+        p.rng_state[px] = rng;
+    }
+}
+
+template <bool VALIDATE>
 __device__ __forceinline__ void finish_pixel(const RenderParams &p, uint32_t x, uint32_t y, bool write, V3 sum,
                                              uint32_t first_prim, uint32_t hash, uint32_t rng, const Counters &cn,
                                              const Counters &per_path, uint32_t n_paths)
 {
-    if (write) {
-        const size_t px = (size_t)y * p.width + x;
-        p.accum[px] = make_float4(sum.x, sum.y, sum.z, 1.0f);
-        const float div = (float)(p.first_frame + p.n_frames - 1u);
-        const uint32_t r = unorm8(sum.x / div), g = unorm8(sum.y / div), b = unorm8(sum.z / div);
-        p.out_rgba8[px] = r | (g << 8) | (b << 16) | 0xFF000000u;
-        if (VALIDATE) {
-            p.hit_ids[px] = first_prim;
-            p.chain_hash[px] = hash;
-            p.rng_state[px] = rng;
-        }
-    }
+    if (write) store_pixel<VALIDATE>(p, x, y, sum, first_prim, hash, rng);
     if (VALIDATE) {
 #pragma unroll
         for (int i = 0; i < 11; i++) {
@@ -319,6 +326,169 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
         }
     }
     finish_pixel<VALIDATE>(p, s.x, s.y, s.in_range, sum, first_prim, hash, rng, cn, none, 0u);
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant 4, for scenes with a hierarchy: persistent waves that stream pixels.
+//
+// With a hierarchy, walks differ in length by orders of magnitude, and a kernel whose lanes are tied
+// to one pixel each (k_regenerate) waits, segment after segment, for the longest walk of the wave;
+// k_paths avoids that but needs several frames per launch to have spare work for its lanes.  Here a
+// lane takes the next pixel from a launch-wide cursor whenever it has finished one (all frames and
+// samples of a pixel stay in one lane, in the shader's order), walks are resumable as in k_paths
+// (all walking lanes step until half of them are done, the finished ones shade and start their next
+// ray), and the only idle lanes are those at the very end of the launch.  Pixels are handed out in
+// 8 x 8 tiles.  p.hit_count is the cursor and must be zero at launch.
+// --------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 64;
+
+template <bool VALIDATE>
+__global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
+{
+    constexpr bool BVH = true;
+    RT_BVH_STACK(kStreamThreads);
+    const uint32_t lane = threadIdx.x;
+    const Sky sky = make_sky(p);
+    const DeviceScene &sc = p.scene;
+    const uint32_t nS = p.sphere_number, nM = p.mesh_number;
+    const uint32_t tiles_x = (p.width + 7u) / 8u, tiles_y = (p.height + 7u) / 8u;
+    const uint32_t n_items = tiles_x * tiles_y * 64u;
+    Counters cn, none;
+    zero(cn);
+    zero(none);
+
+    // the pixel this lane is working on
+    bool has_pixel = false;
+    uint32_t px_x = 0u, px_y = 0u;
+    float px_lin = 0.0f;
+    V3 px_origin = mk(0.0f, 0.0f, 0.0f), px_dir = mk(0.0f, 0.0f, 0.0f);
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    uint32_t hash = 0u, first_prim = kMissId, fh = 0u;
+    // cursor within the pixel: frame f (0-based within the launch), sample k, bounce i
+    uint32_t f = 0u, k = 0u, i = 0u, rng = 0u;
+    V3 o = px_origin, d = px_dir;
+    V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
+    BvhWalk walk;
+    bvh_idle(walk);
+    bool in_walk = false;
+    bool exhausted = false;  // wave-uniform: the cursor has passed the last item
+
+    for (;;) {
+        // ---- lanes without a pixel take the next items
+        const unsigned long long need = __ballot(!has_pixel);
+        if (need != 0ull && !exhausted) {
+            const uint32_t want = (uint32_t)__popcll(need);
+            uint32_t first = 0u;
+            if (lane == 0u) first = atomicAdd(p.hit_count, want);
+            first = (uint32_t)__shfl((int)first, 0, 64);
+            exhausted = first + want >= n_items || first + want < first;
+            const uint32_t item = first + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!has_pixel && item < n_items && item >= first) {
+                const uint32_t tile = item >> 6, j = item & 63u;
+                const uint32_t x = (tile % tiles_x) * 8u + (j & 7u), y = (tile / tiles_x) * 8u + (j >> 3);
+                if (x < p.width && y < p.height) {
+                    const PixelSetup s = pixel_setup_xy(p, x, y, true);
+                    has_pixel = true;
+                    px_x = x;
+                    px_y = y;
+                    px_lin = s.lin;
+                    px_origin = s.origin;
+                    px_dir = s.dir;
+                    sum = load_sum(p, x, y, true);
+                    hash = 0u;
+                    first_prim = kMissId;
+                    fh = frame_hash_init(p.first_frame);
+                    f = 0u;
+                    k = 0u;
+                    i = 0u;
+                    rng = (uint32_t)s.lin + p.first_frame * 719393u;
+                    o = s.origin;
+                    d = s.dir;
+                    light = mk(0.0f, 0.0f, 0.0f);
+                    thr = mk(1.0f, 1.0f, 1.0f);
+                    frame_light = mk(0.0f, 0.0f, 0.0f);
+                    if (VALIDATE) cn.c[9]++;
+                }
+            }
+        }
+        if (__ballot(has_pixel) == 0ull) {
+            if (exhausted) break;
+            continue;  // only pixels outside the image so far
+        }
+
+        // ---- trace: every lane with a pixel holds a ray; walks are resumed where they stopped
+        if (has_pixel && !in_walk) {
+            bvh_begin<VALIDATE>(walk, sc, nS, nM, o, d, cn);
+            in_walk = true;
+        }
+        const uint32_t target = ((uint32_t)__popcll(__ballot(in_walk)) * RT_BVH_KEEP_NUM) >> RT_BVH_KEEP_SHIFT;
+        for (;;) {
+            const bool stepping = in_walk && walk.active();
+            if ((uint32_t)__popcll(__ballot(stepping)) <= target) break;
+            bvh_pass<VALIDATE>(stepping, walk, sc, nS, nM, o, d, cn, bvh_stack, bvh_stride);
+        }
+
+        // ---- lanes whose walk is over: the rest of Trace (Raytracing.comp:417-437) and of main (:464-480)
+        if (in_walk && !walk.active()) {
+            in_walk = false;
+            const Hit h = walk.best;
+            if (VALIDATE) {
+                cn.c[10]++;
+                fh = (fh ^ h.prim) * kHashPrime;
+                if (i == 0u && k == 0u) first_prim = h.prim;
+            }
+            bool path_done;
+            if (h.prim != kMissId) {
+                if (VALIDATE) {
+                    cn.c[6]++;
+                    if (h.prim < nS) cn.c[2]++;
+                    else cn.c[5]++;
+                }
+                bounce(sc, nS, h, o, d, light, thr, rng);
+                i++;
+                path_done = i >= p.max_bounce;
+            } else {
+                if (VALIDATE) cn.c[7]++;
+                light = light + env_light(sky, d) * thr;
+                path_done = true;
+            }
+            if (path_done) {
+                frame_light = frame_light + light;
+                k++;
+                bool more = true;
+                if (k >= p.rays_per_pixel) {
+                    frame_light = average_samples(frame_light, p);
+                    if (VALIDATE) {
+                        cn.c[8]++;
+                        hash += fh;
+                        fh = frame_hash_init(p.first_frame + f + 1u);
+                    }
+                    const uint32_t fi = p.first_frame + f;
+                    sum = (fi == 1u) ? frame_light : sum + frame_light;
+                    frame_light = mk(0.0f, 0.0f, 0.0f);
+                    k = 0u;
+                    f++;
+                    more = f < p.n_frames;
+                    if (more) rng = (uint32_t)px_lin + (p.first_frame + f) * 719393u;
+                } else {
+                    rng += k;
+                }
+                if (more) {
+                    if (VALIDATE) cn.c[9]++;
+                    o = px_origin;
+                    d = px_dir;
+                    light = mk(0.0f, 0.0f, 0.0f);
+                    thr = mk(1.0f, 1.0f, 1.0f);
+                    i = 0u;
+                } else {
+                    store_pixel<VALIDATE>(p, px_x, px_y, sum, first_prim, hash, rng);
+                    has_pixel = false;
+                }
+            }
+        }
+    }
+    // the wave's event counters
+    finish_pixel<VALIDATE>(p, 0u, 0u, false, sum, 0u, 0u, 0u, cn, none, 0u);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -633,6 +803,7 @@ const char *rt_kernel_name(int variant)
     case 0: return "k_megakernel";
     case 1: return "k_regenerate";
     case 2: return "k_classify+k_paths";
+    case 4: return "k_stream";
     default: return "unknown";
     }
 }
@@ -644,9 +815,10 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     const dim3 block(kBlockThreads, 1, 1);
     // the flattened loops assume every path has at least one segment; the cached first bounce
     // assumes at least one more after it
-    if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
-    if (variant == 1 && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
     const bool bvh = p.use_bvh != 0u;
+    if (variant == 4 && (!bvh || !p.hit_count)) variant = 1;  // the streaming kernel exists for hierarchy scenes only
+    if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
+    if ((variant == 1 || variant == 4) && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
 #define RT_LAUNCH(KERNEL, GRID, BLOCK)                                                                    \
     do {                                                                                                  \
         if (validate && bvh) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, stream, p);         \
@@ -691,6 +863,19 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
             RT_LAUNCH(k_paths, grid_paths, block_paths);
         }
 #undef RT_LAUNCH
+    } else if (variant == 4) {
+        if (cache != RT_CACHE_NONE) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        // as many single-wave workgroups as the device keeps resident (more would only queue up)
+        int device = 0, cus = 0;
+        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+        const uint32_t n_tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
+        const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * 16u;
+        const dim3 grid_stream(n_tiles < resident ? n_tiles : resident, 1, 1);
+        if (validate) hipLaunchKernelGGL(k_stream<true>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else hipLaunchKernelGGL(k_stream<false>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }

@@ -458,8 +458,7 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     int variant = c->variant;
     RtCacheUse cache = RT_CACHE_NONE;
     if (variant == RTMI_VARIANT_AUTO) {
-        // measured at 1080p: REGENERATE is ahead up to 8 paths per pixel per launch, COMPACT from 16 on;
-        // with a hierarchy only COMPACT's kernel lets finished lanes go on while others still walk
+        // measured at 1080p: REGENERATE is ahead up to 8 paths per pixel per launch, COMPACT from 16 on
         const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
         const bool compact_runs = fd->max_bounce_limit >= 2 && fd->rays_per_pixel >= 1;  // else the launcher falls back
         rtmi_frame_data key = *fd;
@@ -469,8 +468,12 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
         // 12 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
         // 0.59; 2 paths: 0.23 against 0.20); below 8 the one-lane-per-pixel kernel starts from them.
-        const bool use_store = compact_runs && !c->validate;
-        const bool compact = c->bvh_active || paths_per_pixel >= (use_store ? 8u : 12u);
+        // With a hierarchy COMPACT needs about 8 paths per pixel to keep its lanes fed (10^6 + 10^6 primitive
+        // scene at 1080p: 1 frame 27 ms against STREAM's 12.5, 4 frames 53 against 47, 8 frames 93 against 93,
+        // 16 frames 173 against 188); below that the pixel-streaming kernel runs, which starts from nothing stored.
+        const bool stream = c->bvh_active && paths_per_pixel < 8u;
+        const bool use_store = compact_runs && !c->validate && !stream;
+        const bool compact = !stream && (c->bvh_active || paths_per_pixel >= (use_store ? 8u : 12u));
         if (use_store) {
             const size_t np = n_pixels(c);
             if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
@@ -478,7 +481,7 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
             // the work list is only needed (and only built) by COMPACT
             cache = (same_as_stored && (!compact || c->cache_has_list)) ? RT_CACHE_LOAD : RT_CACHE_STORE;
         }
-        variant = compact ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
+        variant = stream ? RTMI_VARIANT_STREAM : compact ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
         if (cache == RT_CACHE_STORE) {
             c->cache_key = key;
             c->cache_generation = c->scene_generation;
@@ -521,7 +524,7 @@ int rtmi_set_variant(rtmi_ctx *c, int variant)
 {
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     if (variant != RTMI_VARIANT_MEGAKERNEL && variant != RTMI_VARIANT_REGENERATE && variant != RTMI_VARIANT_COMPACT &&
-        variant != RTMI_VARIANT_AUTO)
+        variant != RTMI_VARIANT_AUTO && variant != RTMI_VARIANT_STREAM)
         return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_variant: variant %d not available", variant);
     c->variant = variant;
     return RTMI_OK;

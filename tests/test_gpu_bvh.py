@@ -129,7 +129,7 @@ def test_ties_keep_the_loop_order(rtmi, oracle):
     _assert_rays_equal(bvh, _hits(rtmi, sc, rtmi.abi.ACCEL_NONE, o, d), "duplicated primitives, exhaustive kernels")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_render_matches_oracle(rtmi, oracle, variant):
     sc, pose = _small_stress(rtmi)
     osc = oracle.Scene.from_product(sc)
@@ -154,6 +154,26 @@ def test_render_matches_oracle(rtmi, oracle, variant):
         assert cn[k] == want["counters"][k], k
     assert 0 < cn["n_sphere_tests"] < want["counters"]["n_sphere_tests"] // 20
     assert 0 < cn["n_tri_tests"] < want["counters"]["n_tri_tests"] // 20
+
+
+def test_stream_variant_matches_compact_across_launches(rtmi):
+    """The pixel-streaming kernel against the compacting one, without validation, on an image whose
+    sides are not multiples of the 8 x 8 hand-out tile, over launches that continue a running sum."""
+    sc, pose = _small_stress(rtmi, seed=4242)
+    w, h = 100, 52
+    fd = rtmi.make_frame_data(w, h, sc, pose=pose, rays_per_pixel=3, max_bounce=16)
+    out = {}
+    for variant in (rtmi.abi.VARIANT_STREAM, rtmi.abi.VARIANT_COMPACT):
+        with rtmi.Renderer(w, h, variant=variant) as r:
+            r.set_acceleration(rtmi.abi.ACCEL_BVH)
+            r.upload_scene(sc)
+            r.render_frames(fd, 1, 1)
+            first = r.read_accum()
+            r.render_frames(fd, 2, 3)
+            out[variant] = (first, r.read_accum(), r.read_output_rgba8())
+    a, b = out[rtmi.abi.VARIANT_STREAM], out[rtmi.abi.VARIANT_COMPACT]
+    assert cases.bits_equal(a[0], b[0]) and cases.bits_equal(a[1], b[1]) and (a[2] == b[2]).all()
+    assert (a[1][..., 3] == 1.0).all() and np.abs(a[1][..., :3]).sum() > 0
 
 
 def test_render_matches_exhaustive_kernels_without_validation(rtmi):

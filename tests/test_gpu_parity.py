@@ -11,7 +11,7 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 3]   # 3 = chosen per launch
+VARIANTS = [0, 1, 2, 3, 4]   # 3 = chosen per launch
 
 
 def gpu_render(rtmi, case, variant, validate=True, per_frame=False):
