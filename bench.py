@@ -230,6 +230,9 @@ def main():
         "msegments_per_s": counters["n_segments"] / (kernel_ms * 1e-3) / 1e6,
         "counters_rank0_launch": counters,
     }
+    if traffic is not None:
+        # what the counters saw reach the memory side, at this run's launch time
+        result["roofline"]["hbm_gbs_from_traffic"] = traffic / (kernel_ms * 1e-3) / 1e9
     if renderer.acceleration() == R.abi.ACCEL_BVH:
         # The hierarchy walk is a chain of dependent 64-byte gathers, bound by the memory system and not
         # by arithmetic: price it by the bytes the walk has to fetch (two child boxes per node visit, a
@@ -243,7 +246,8 @@ def main():
             "algorithmic_gather_bytes_per_launch": gather_bytes, "node_visits_per_launch": node_visits,
             "fp32_tflops_algorithmic": achieved_tflops,
             "note": "hierarchy traversal: algorithmic bytes are the node and primitive records the walk fetches "
-                    "(served largely by L2 / Infinity Cache, so they bound cache traffic, not HBM traffic)",
+                    "(most are served by L2 / Infinity Cache: compare hbm_gbs_from_traffic, the part that "
+                    "reaches the memory side, so achieved / peak overstates how close the kernel is to the HBM limit)",
         })
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds)
