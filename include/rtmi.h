@@ -103,7 +103,7 @@ typedef enum rtmi_variant {
     RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 12 paths per pixel
                                       (frames x rays per pixel), REGENERATE otherwise (COMPACT spends about 0.4 ms
                                       per 1080p launch on classification, which a one-frame launch, the reference's
-                                      own calling pattern, does not earn back); with a hierarchy, STREAM below 8
+                                      own calling pattern, does not earn back); with a hierarchy, STREAM below 16
                                       paths per pixel and COMPACT from there on.
                                       While the uniform block (apart from frame_index) and the scene stay the same
                                       from launch to launch, AUTO also keeps every pixel's primary segment and lets

@@ -372,6 +372,15 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
     bvh_idle(walk);
     bool in_walk = false;
     bool exhausted = false;  // wave-uniform: the cursor has passed the last item
+    // The shader casts the same primary ray for every sample of a pixel (Raytracing.comp:449-453): the
+    // closest hit of the pixel's first path is kept and its later paths start from it without a walk.
+    Hit primary;
+    primary.t = 0.0f;
+    primary.prim = kMissId;
+    primary.mat = 0u;
+    primary.u = 0.0f;
+    primary.v = 0.0f;
+    bool have_primary = false;
 
     for (;;) {
         // ---- lanes without a pixel take the next items
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
                     light = mk(0.0f, 0.0f, 0.0f);
                     thr = mk(1.0f, 1.0f, 1.0f);
                     frame_light = mk(0.0f, 0.0f, 0.0f);
+                    have_primary = false;
                     if (VALIDATE) cn.c[9]++;
                 }
             }
@@ -417,7 +427,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
         }
 
         // ---- trace: every lane with a pixel holds a ray; walks are resumed where they stopped
-        if (has_pixel && !in_walk) {
+        const bool from_primary = has_pixel && !in_walk && i == 0u && have_primary;
+        if (has_pixel && !in_walk && !from_primary) {
             bvh_begin<VALIDATE>(walk, sc, nS, nM, o, d, cn);
             in_walk = true;
         }
@@ -429,9 +440,14 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
         }
 
         // ---- lanes whose walk is over: the rest of Trace (Raytracing.comp:417-437) and of main (:464-480)
-        if (in_walk && !walk.active()) {
-            in_walk = false;
-            const Hit h = walk.best;
+        const bool walked = in_walk && !walk.active();
+        if (walked || from_primary) {
+            in_walk = in_walk && !walked;
+            const Hit h = walked ? walk.best : primary;
+            if (walked && i == 0u) {
+                primary = h;
+                have_primary = true;
+            }
             if (VALIDATE) {
                 cn.c[10]++;
                 fh = (fh ^ h.prim) * kHashPrime;
