@@ -832,7 +832,9 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     // the flattened loops assume every path has at least one segment; the cached first bounce
     // assumes at least one more after it
     const bool bvh = p.use_bvh != 0u;
-    if (variant == 4 && (!bvh || !p.hit_count)) variant = 1;  // the streaming kernel exists for hierarchy scenes only
+    // the streaming kernel exists for hierarchy scenes only, and its 32-bit cursor counts whole 8 x 8 tiles
+    const uint64_t stream_items = (uint64_t)((p.width + 7u) / 8u) * ((p.height + 7u) / 8u) * 64u;
+    if (variant == 4 && (!bvh || !p.hit_count || stream_items > 0xF0000000ull)) variant = 1;
     if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
     if ((variant == 1 || variant == 4) && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
 #define RT_LAUNCH(KERNEL, GRID, BLOCK)                                                                    \
