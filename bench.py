@@ -101,8 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_spheres", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1, 16 for c5)")
-    ap.add_argument("--variant", type=int, default=2,
-                    help="0 nested megakernel, 1 regenerating megakernel, 2 classify + wave-cooperative paths (default)")
+    ap.add_argument("--variant", type=int, default=None, choices=[0, 1, 2, 4],
+                    help="0 nested megakernel, 1 regenerating megakernel, 2 classify + wave-cooperative paths (default), "
+                         "4 pixel-streaming kernel (hierarchy scenes; default for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -137,6 +138,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     scene_name, width, height, max_bounce = WORKLOADS[args.workload]
+    if args.variant is None:
+        args.variant = 4 if args.workload.startswith("c5") else 2
     frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 16}.get(args.workload, 256)
     scene, pose = build_scene(R, scene_name)
     fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
@@ -207,14 +210,14 @@ def main():
                         "max depth %d, bench pose" % (args.workload, scene_name, scene.n_spheres, scene.n_triangles,
                                                       scene.n_meshes, width, height, frames, max_bounce),
             "closest_hit": "hierarchy" if renderer.acceleration() == R.abi.ACCEL_BVH else "exhaustive loops",
-            "variant": ["megakernel", "regenerate", "compact"][args.variant],
+            "variant": {0: "megakernel", 1: "regenerate", 2: "compact", 4: "stream"}[args.variant],
             "frames_per_gpu": frames, "total_frames": total_frames,
             "parallelism": "frame-range split x%d + RCCL all-reduce(sum) of float4 accumulation" % world if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "fp32_valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": ["k_megakernel", "k_regenerate", "k_classify+k_paths (k_paths dominates)"][args.variant],
+            "kernel": {0: "k_megakernel", 1: "k_regenerate", 2: "k_classify+k_paths (k_paths dominates)", 4: "k_stream"}[args.variant],
             "kernel_ms": kernel_ms, "launches_timed": launches,
             "algorithmic_flops_per_launch": flops_per_launch,
             "algorithmic_hbm_bytes_per_launch": algorithmic_bytes,

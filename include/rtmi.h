@@ -103,16 +103,14 @@ typedef enum rtmi_variant {
     RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 12 paths per pixel
                                       (frames x rays per pixel), REGENERATE otherwise (COMPACT spends about 0.4 ms
                                       per 1080p launch on classification, which a one-frame launch, the reference's
-                                      own calling pattern, does not earn back); with a hierarchy, STREAM below 16
-                                      paths per pixel and COMPACT from there on.
+                                      own calling pattern, does not earn back); with a hierarchy, STREAM.
                                       While the uniform block (apart from frame_index) and the scene stay the same
                                       from launch to launch, AUTO also keeps every pixel's primary segment and lets
                                       later launches start from it; results are the same bits either way */
     RTMI_VARIANT_STREAM     = 4    /* scenes with a hierarchy: persistent waves whose lanes take pixel after pixel from
                                       a launch-wide cursor and resume their walks, so that no lane waits for the
-                                      longest walk of its wave; for launches of few frames (COMPACT needs several
-                                      frames per launch to keep its lanes fed).  Without a hierarchy it runs as
-                                      REGENERATE */
+                                      longest walk of its wave (COMPACT needs several frames per launch to keep
+                                      its lanes fed).  Without a hierarchy it runs as REGENERATE */
 } rtmi_variant;
 
 /* How ClosestHit (RT.comp:338-388) finds its candidates.  The reference loops over every sphere and

@@ -341,9 +341,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
 // 8 x 8 tiles.  p.hit_count is the cursor and must be zero at launch.
 // --------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 64;
+#ifndef RT_STREAM_MIN_WAVES
+#define RT_STREAM_MIN_WAVES 5
+#endif
+constexpr uint32_t kStreamWavesPerCu = RT_STREAM_MIN_WAVES > 4 ? 4u * RT_STREAM_MIN_WAVES : 16u;
 
 template <bool VALIDATE>
-__global__ __launch_bounds__(kStreamThreads) void k_stream(const RenderParams p)
+__global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(const RenderParams p)
 {
     constexpr bool BVH = true;
     RT_BVH_STACK(kStreamThreads);
@@ -890,7 +894,7 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
         if ((e = hipGetDevice(&device)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
         const uint32_t n_tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
-        const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * 16u;
+        const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * kStreamWavesPerCu;
         const dim3 grid_stream(n_tiles < resident ? n_tiles : resident, 1, 1);
         if (validate) hipLaunchKernelGGL(k_stream<true>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
         else hipLaunchKernelGGL(k_stream<false>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);

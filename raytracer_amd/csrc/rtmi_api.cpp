@@ -468,11 +468,10 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
         // 12 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
         // 0.59; 2 paths: 0.23 against 0.20); below 8 the one-lane-per-pixel kernel starts from them.
-        // With a hierarchy COMPACT needs about 16 paths per pixel to keep its lanes fed (10^6 + 10^6 primitive
-        // scene at 1080p: 1 frame 27 ms against STREAM's 12.5, 4 frames 53 against 45, 8 frames 93 against 89,
-        // 16 frames 172 against 175, 64 frames 643 against 696); below that the pixel-streaming kernel runs,
-        // which starts from nothing stored.
-        const bool stream = c->bvh_active && paths_per_pixel < 16u;
+        // With a hierarchy the pixel-streaming kernel is ahead at every launch size (10^6 + 10^6 primitive
+        // scene at 1080p: 1 frame 11.4 ms against COMPACT's 27, 8 frames 80 against 93, 16 frames 158 against
+        // 172, 64 frames 630 against 643); it starts from nothing stored.
+        const bool stream = c->bvh_active;
         const bool use_store = compact_runs && !c->validate && !stream;
         const bool compact = !stream && (c->bvh_active || paths_per_pixel >= (use_store ? 8u : 12u));
         if (use_store) {

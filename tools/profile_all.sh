@@ -11,14 +11,15 @@ mkdir -p $OUT
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/ks_bench -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/bench_under_trace.err
 cat $(find $OUT/ks_bench -name "*kernel_stats.csv") > $OUT/kernel_stats_c2.csv
 # 2. other workloads
+variant_of() { case $1 in c5_*) echo 4;; *) echo 2;; esac; }  # hierarchy scenes: the pixel-streaming kernel
 for wl in c3_mesh c4_mesh_4k c5_stress; do
-  timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/ks_$wl -o $wl --output-format csv -- python3 tools/run_workload.py $wl 2 4 > $OUT/run_$wl.log 2>&1
+  timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/ks_$wl -o $wl --output-format csv -- python3 tools/run_workload.py $wl $(variant_of $wl) 4 > $OUT/run_$wl.log 2>&1
   cat $(find $OUT/ks_$wl -name "*kernel_stats.csv") > $OUT/kernel_stats_$wl.csv
 done
 # 3. PMC passes (c2 default workload: 2 launches of 256 frames)
 pmc() { # name workload counters...
   name=$1; wl=$2; shift; shift
-  timeout -s KILL 170 rocprofv3 --pmc "$@" -d $OUT/pmc_$wl/$name -o $name --output-format csv -- python3 tools/run_workload.py $wl 2 2 > $OUT/pmc_${wl}_$name.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc "$@" -d $OUT/pmc_$wl/$name -o $name --output-format csv -- python3 tools/run_workload.py $wl $(variant_of $wl) 2 > $OUT/pmc_${wl}_$name.log 2>&1
 }
 for wl in c2_spheres c5_stress; do
   pmc sq1 $wl SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU
