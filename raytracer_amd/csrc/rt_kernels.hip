@@ -364,13 +364,13 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
     // the pixel this lane is working on
     bool has_pixel = false;
     uint32_t px_x = 0u, px_y = 0u;
-    float px_lin = 0.0f;
-    V3 px_origin = mk(0.0f, 0.0f, 0.0f), px_dir = mk(0.0f, 0.0f, 0.0f);
+    const V3 origin = mk(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);  // the same for every pixel
+    V3 px_dir = mk(0.0f, 0.0f, 0.0f);
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     uint32_t hash = 0u, first_prim = kMissId, fh = 0u;
     // cursor within the pixel: frame f (0-based within the launch), sample k, bounce i
     uint32_t f = 0u, k = 0u, i = 0u, rng = 0u;
-    V3 o = px_origin, d = px_dir;
+    V3 o = origin, d = px_dir;
     V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
     BvhWalk walk;
     bvh_idle(walk);
@@ -404,8 +404,6 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                     has_pixel = true;
                     px_x = x;
                     px_y = y;
-                    px_lin = s.lin;
-                    px_origin = s.origin;
                     px_dir = s.dir;
                     sum = load_sum(p, x, y, true);
                     hash = 0u;
@@ -489,13 +487,14 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                     k = 0u;
                     f++;
                     more = f < p.n_frames;
-                    if (more) rng = (uint32_t)px_lin + (p.first_frame + f) * 719393u;
+                    // the float part of the seed, Raytracing.comp:462
+                    if (more) rng = (uint32_t)((float)px_x + p.window_w * (float)px_y) + (p.first_frame + f) * 719393u;
                 } else {
                     rng += k;
                 }
                 if (more) {
                     if (VALIDATE) cn.c[9]++;
-                    o = px_origin;
+                    o = origin;
                     d = px_dir;
                     light = mk(0.0f, 0.0f, 0.0f);
                     thr = mk(1.0f, 1.0f, 1.0f);
