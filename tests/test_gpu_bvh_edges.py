@@ -32,27 +32,29 @@ def scene(rtmi, oracle):
     return sc, oracle.Scene.from_product(sc), pose
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_more_frames_than_the_ring(rtmi, oracle, scene, variant):
     sc, osc, pose = scene
     got, want = _render_both(rtmi, oracle, sc, osc, pose, 48, 27, 1, 12, 1, 11, variant)
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("variant", [2, 4])
 @pytest.mark.parametrize("max_bounce", [0, 1, 2, 3])
-def test_small_bounce_limits(rtmi, oracle, scene, max_bounce):
+def test_small_bounce_limits(rtmi, oracle, scene, max_bounce, variant):
     sc, osc, pose = scene
-    got, want = _render_both(rtmi, oracle, sc, osc, pose, 40, 24, 2, max_bounce, 1, 3, 2)
+    got, want = _render_both(rtmi, oracle, sc, osc, pose, 40, 24, 2, max_bounce, 1, 3, variant)
     assert_same(got, want)
 
 
-def test_samples_per_pixel_and_continued_sum(rtmi, oracle, scene):
+@pytest.mark.parametrize("variant", [2, 4])
+def test_samples_per_pixel_and_continued_sum(rtmi, oracle, scene, variant):
     sc, osc, pose = scene
     w, h = 37, 19                                   # not a multiple of the tile or the wave
     rs = np.random.RandomState(2)
     seed = rs.uniform(0.0, 4.0, size=(h, w, 4)).astype(np.float32)
     seed[..., 3] = 1.0
-    got, want = _render_both(rtmi, oracle, sc, osc, pose, w, h, 3, 7, 5, 6, 2, seed_accum=seed)
+    got, want = _render_both(rtmi, oracle, sc, osc, pose, w, h, 3, 7, 5, 6, variant, seed_accum=seed)
     assert_same(got, want)
 
 
@@ -70,3 +72,12 @@ def test_frame_loop_equals_batched_launch(rtmi, scene):
             r.render(fd)
         looped = (r.read_accum(), r.read_output_rgba8())
     assert cases.bits_equal(batched[0], looped[0]) and np.array_equal(batched[1], looped[1])
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (9, 17)])
+def test_images_smaller_than_a_tile(rtmi, oracle, scene, size):
+    """The streaming kernel hands pixels out in 8 x 8 tiles; images that do not fill one, or end in
+    partial ones, must come out like any other."""
+    sc, osc, pose = scene
+    got, want = _render_both(rtmi, oracle, sc, osc, pose, size[0], size[1], 2, 6, 1, 3, 4)
+    assert_same(got, want)
