@@ -33,7 +33,7 @@ struct Options {
 void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
-              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3] [--batch]\n"
+              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3|4] [--batch]\n"
               "              [--move-at FRAME] [--device N] [--fan]\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
               "              [--script FILE]      camera input, one line per run of frames:\n"
