@@ -214,8 +214,9 @@ def test_degenerate_scenes(rtmi, oracle):
 def test_full_size_stress_scene(rtmi, oracle):
     """The 10^6-sphere + 10^6-triangle scene itself: closest hits of random rays against the oracle's
     exhaustive loops (a few thousand rays are affordable), and two properties that need no oracle: the
-    nested-loop kernel (one uninterrupted walk per segment) and the wave-cooperative kernel (walks
-    stopped and resumed) give the same image, and so does splitting the frames over two launches."""
+    nested-loop kernel (one uninterrupted walk per segment) and the wave-cooperative and pixel-streaming
+    kernels (walks stopped and resumed) give the same image, and so does splitting the frames over two
+    launches.  At 1920 x 1080 the two resuming kernels are compared with each other."""
     sc, pose = rtmi.scenes.stress_scene()
     assert (sc.n_spheres, sc.n_triangles, sc.n_meshes) == (1000000, 1000000, 16)
     osc = oracle.Scene.from_product(sc)
@@ -223,7 +224,7 @@ def test_full_size_stress_scene(rtmi, oracle):
     w, h = 96, 54
     fd = rtmi.make_frame_data(w, h, sc, pose=pose, rays_per_pixel=1, max_bounce=16)
     out = {}
-    for variant in (0, 2):
+    for variant in (0, 2, 4):
         with rtmi.Renderer(w, h, variant=variant) as r:
             r.upload_scene(sc)
             assert r.acceleration() == rtmi.abi.ACCEL_BVH
@@ -238,7 +239,16 @@ def test_full_size_stress_scene(rtmi, oracle):
                 r.render_frames(fd, 2, 3)
                 out["split"] = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8())
     assert_same(out[2], out[0])
+    assert_same(out[4], out[0])
     assert_same(out["split"], out[2], keys=("rgba8",))
     assert int((out[2]["prim_id"] != rtmi.abi.MISS_ID).sum()) > w * h // 2
     assert int((rays[1] != rtmi.abi.MISS_ID).sum()) > 500
     _assert_rays_equal(rays, oracle.closest_hit(osc, o, d), "full stress scene")
+    big = {}
+    fd = rtmi.make_frame_data(1920, 1080, sc, pose=pose, rays_per_pixel=1, max_bounce=16)
+    for variant in (2, 4):
+        with rtmi.Renderer(1920, 1080, variant=variant) as r:
+            r.upload_scene(sc)
+            r.render_frames(fd, 1, 2)
+            big[variant] = (r.read_accum(), r.read_output_rgba8())
+    assert cases.bits_equal(big[2][0], big[4][0]) and np.array_equal(big[2][1], big[4][1])
