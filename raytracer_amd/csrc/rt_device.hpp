@@ -263,8 +263,7 @@ struct Counters {
 // only needed for the winner (hit point, normal, material) left to the caller.  Primitive loops are
 // wave-uniform: record fetches are scalar, lanes differ only in the ray.
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes,
-                                           V3 o, V3 d, Counters &cn)
+__device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32_t n_spheres, V3 o, V3 d, Counters &cn)
 {
     Hit best;
     best.t = kFltMax;
@@ -359,23 +358,74 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
         }
     }
 
-    // RayBox gate + RayTriangle, Raytracing.comp:352-368, 311-336, 286-309
+    return best;
+}
+
+// One triangle of RayTriangle (Raytracing.comp:286-309) against the best hit so far: best is replaced
+// when the shader's own sequence accepts the triangle with a smaller t.  P, AB, AC, N are the 64-byte
+// intersection record {p1} {AB} {AC} {AB x AC}; prim and mat are what a win records.
+__device__ __forceinline__ void triangle_candidate(const float4 P, const float4 AB, const float4 AC, const float4 N, V3 o, V3 d,
+                                                   uint32_t prim, uint32_t mat, Hit &best)
+{
+    const float det = -dot(d, mk(N.x, N.y, N.z));
+    if (det >= 1e-6f) {
+        // numerators of t, u, v (Raytracing.comp:291-299 before the multiply by 1/det)
+        const V3 ao = o - mk(P.x, P.y, P.z);
+        const V3 dao = cross(ao, d);
+        const float tn = dot(ao, mk(N.x, N.y, N.z));
+        const float un = dot(mk(AC.x, AC.y, AC.z), dao);
+        const float vn = -dot(mk(AB.x, AB.y, AB.z), dao);
+        // 1/det is positive and at least 2^-128, so a numerator below -2^-20 gives a
+        // product below zero (no underflow to -0); u + v exceeds 1 by 2^-11 or more when
+        // un + vn > det (1 + 2^-10); t is beyond the best when tn > best.t det (1 + 2^-10).
+        // Each of these makes the shader's test fail, so the divide is only made for
+        // lanes that none of them rules out.
+        const float lim = det * 1.0009765625f;
+        const bool ruled_out = (tn < -9.5367431640625e-7f) | (un < -9.5367431640625e-7f) |
+                               (vn < -9.5367431640625e-7f) | (un + vn > lim) | (tn > best.t * lim);
+        if (!ruled_out) {
+            const float inv = 1.0f / det;
+            const float t = tn * inv;
+            const float u = un * inv;
+            const float v = vn * inv;
+            const float w = 1.0f - u - v;
+            if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
+                best.t = t;
+                best.prim = prim;
+                best.mat = mat;
+                best.u = u;
+                best.v = v;
+            }
+        }
+    }
+}
+
+// RayBox (Raytracing.comp:311-336) with the reciprocal direction f = 1 / d
+__device__ __forceinline__ bool mesh_gate(const float4 lo, const float4 hi, V3 o, V3 f)
+{
+    float t1 = (lo.x - o.x) * f.x;
+    float t2 = (hi.x - o.x) * f.x;
+    float t3 = (lo.y - o.y) * f.y;
+    float t4 = (hi.y - o.y) * f.y;
+    float t5 = (lo.z - o.z) * f.z;
+    float t6 = (hi.z - o.z) * f.z;
+    float tmin = gmax(gmax(gmin(t1, t2), gmin(t3, t4)), gmin(t5, t6));
+    float tmax = gmin(gmin(gmax(t1, t2), gmax(t3, t4)), gmax(t5, t6));
+    return !(tmax < 0.0f) && !(tmin > tmax);
+}
+
+// The mesh part of ClosestHit: RayBox gate + RayTriangle per mesh, Raytracing.comp:352-368.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_meshes(Hit &best, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o,
+                                                   V3 d, Counters &cn)
+{
     if (n_meshes > 0) {
-        const float fx = 1.0f / d.x, fy = 1.0f / d.y, fz = 1.0f / d.z;
+        const V3 f = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         for (uint32_t m = 0; m < n_meshes; m++) {
             const float4 lo = ld_uniform(sc.mesh_box, 2 * m + 0);
             const float4 hi = ld_uniform(sc.mesh_box, 2 * m + 1);
-            float t1 = (lo.x - o.x) * fx;
-            float t2 = (hi.x - o.x) * fx;
-            float t3 = (lo.y - o.y) * fy;
-            float t4 = (hi.y - o.y) * fy;
-            float t5 = (lo.z - o.z) * fz;
-            float t6 = (hi.z - o.z) * fz;
-            float tmin = gmax(gmax(gmin(t1, t2), gmin(t3, t4)), gmin(t5, t6));
-            float tmax = gmin(gmin(gmax(t1, t2), gmax(t3, t4)), gmax(t5, t6));
             if (COUNT) cn.c[3]++;
-            const bool inside = !(tmax < 0.0f) && !(tmin > tmax);
-            if (inside) {
+            if (mesh_gate(lo, hi, o, f)) {
                 const uint32_t start = __float_as_uint(lo.w);
                 const uint32_t count = __float_as_uint(hi.w);
                 for (uint32_t j = start; j < start + count; j++) {
@@ -385,41 +435,20 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
                     const float4 AC = ld_uniform(sc.tri_isect, 4 * j + 2);
                     const float4 N = ld_uniform(sc.tri_isect, 4 * j + 3);
                     if (COUNT) cn.c[4]++;
-                    const float det = -dot(d, mk(N.x, N.y, N.z));
-                    if (det >= 1e-6f) {
-                        // numerators of t, u, v (Raytracing.comp:291-299 before the multiply by 1/det)
-                        const V3 ao = o - mk(P.x, P.y, P.z);
-                        const V3 dao = cross(ao, d);
-                        const float tn = dot(ao, mk(N.x, N.y, N.z));
-                        const float un = dot(mk(AC.x, AC.y, AC.z), dao);
-                        const float vn = -dot(mk(AB.x, AB.y, AB.z), dao);
-                        // 1/det is positive and at least 2^-128, so a numerator below -2^-20 gives a
-                        // product below zero (no underflow to -0); u + v exceeds 1 by 2^-11 or more when
-                        // un + vn > det (1 + 2^-10); t is beyond the best when tn > best.t det (1 + 2^-10).
-                        // Each of these makes the shader's test fail, so the divide is only made for
-                        // lanes that none of them rules out.
-                        const float lim = det * 1.0009765625f;
-                        const bool ruled_out = (tn < -9.5367431640625e-7f) | (un < -9.5367431640625e-7f) |
-                                               (vn < -9.5367431640625e-7f) | (un + vn > lim) | (tn > best.t * lim);
-                        if (!ruled_out) {
-                            const float inv = 1.0f / det;
-                            const float t = tn * inv;
-                            const float u = un * inv;
-                            const float v = vn * inv;
-                            const float w = 1.0f - u - v;
-                            if (t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f && t < best.t) {
-                                best.t = t;
-                                best.prim = n_spheres + j;
-                                best.mat = sc.n_spheres + m;  // material rows follow the uploaded sphere count
-                                best.u = u;
-                                best.v = v;
-                            }
-                        }
-                    }
+                    // material rows follow the uploaded sphere count
+                    triangle_candidate(P, AB, AC, N, o, d, n_spheres + j, sc.n_spheres + m, best);
                 }
             }
         }
     }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes,
+                                           V3 o, V3 d, Counters &cn)
+{
+    Hit best = closest_hit_spheres<COUNT>(sc, n_spheres, o, d, cn);
+    closest_hit_meshes<COUNT>(best, sc, n_spheres, n_meshes, o, d, cn);
     return best;
 }
 
