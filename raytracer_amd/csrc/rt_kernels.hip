@@ -16,10 +16,12 @@
 //                  compacted pixels and its lanes share all (pixel, frame) work items of those pixels,
 //                  a lane that finishes an item taking the wave's next one, while per-frame results
 //                  pass through a small LDS ring so that every pixel's sum is still formed in frame
-//                  order;
+//                  order, and the triangle tests of a mesh are spread over the lanes of the wave;
 //   k_stream       (scenes with a hierarchy) persistent waves whose lanes take pixel after pixel from a
 //                  launch-wide cursor and resume their walks through the hierarchy.
 #include "rt_kernels.hpp"
+
+#include <type_traits>
 
 #include "rt_device.hpp"
 #include "rt_bvh_device.hpp"
@@ -868,10 +870,18 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
         const uint32_t n_pixels = p.width * p.height;
         const dim3 grid_paths((n_pixels + 63u) / 64u, 1, 1);
         const dim3 block_paths(kPathsThreads, 1, 1);
+        // k_paths for this scene: with a hierarchy, without meshes (no mesh code at all), or with meshes
+        // (triangle tests shared by the lanes of a wave)
+        const bool meshes = p.mesh_number != 0u;
+        auto launch_paths = [&](auto validate_c, auto cached_c) {
+            constexpr bool V = decltype(validate_c)::value, C = decltype(cached_c)::value;
+            if (bvh) hipLaunchKernelGGL((k_paths<V, true, C, true>), grid_paths, block_paths, 0, stream, p);
+            else if (meshes) hipLaunchKernelGGL((k_paths<V, false, C, true>), grid_paths, block_paths, 0, stream, p);
+            else hipLaunchKernelGGL((k_paths<V, false, C, false>), grid_paths, block_paths, 0, stream, p);
+        };
         if (cache == RT_CACHE_LOAD) {
             hipLaunchKernelGGL(k_sky_add, dim3((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1), block, 0, stream, p);
-            if (bvh) hipLaunchKernelGGL((k_paths<false, true, true>), grid_paths, block_paths, 0, stream, p);
-            else hipLaunchKernelGGL((k_paths<false, false, true>), grid_paths, block_paths, 0, stream, p);
+            launch_paths(std::false_type{}, std::true_type{});
         } else {
             hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
@@ -881,7 +891,8 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
             } else {
                 RT_LAUNCH(k_classify, grid, block);
             }
-            RT_LAUNCH(k_paths, grid_paths, block_paths);
+            if (validate) launch_paths(std::true_type{}, std::false_type{});
+            else launch_paths(std::false_type{}, std::false_type{});
         }
 #undef RT_LAUNCH
     } else if (variant == 4) {

@@ -163,6 +163,41 @@ def test_edge_shapes_and_empty_scenes(rtmi, oracle, variant):
         assert cases.bits_equal(r.read_accum(), oracle.render(ofd, osc, 1, 2)["accum"])
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_duplicated_triangles_and_overlapping_meshes(rtmi, oracle, variant):
+    """Every triangle of the reference scene twice in a row (each hit is then a tie between two
+    neighbouring indices, which the wave-shared triangle tests hand to different lanes) and the cube's
+    mesh record listed a second time: the lowest index of the first mesh must win every time."""
+    case = dict(cases.CASES["c3_mesh_bench_pose"], size=(80, 45), n=3)
+    base = cases.product_scene(case)
+    ns, nt, nm = base.n_spheres, base.n_triangles, base.n_meshes
+    sph = np.frombuffer(base.sphere_array(), dtype=rtmi.host.SPHERE_DTYPE, count=ns)
+    tri = np.frombuffer(base.triangles, dtype=rtmi.host.TRIANGLE_DTYPE, count=nt)
+    msh = np.frombuffer(base.meshes, dtype=rtmi.host.MESH_DTYPE, count=nm)
+    tri2 = np.repeat(tri, 2)                                   # t0 t0 t1 t1 ...
+    msh2 = np.concatenate([msh, msh[-1:]]).copy()
+    msh2["start_triangle"] = np.concatenate([2 * msh["start_triangle"], 2 * msh["start_triangle"][-1:]])
+    msh2["num_triangles"] = np.concatenate([2 * msh["num_triangles"], 2 * msh["num_triangles"][-1:]])
+    sc = rtmi.Scene.from_records(sph, tri2, msh2)
+    osc = oracle.Scene.from_product(sc)
+    w, h = case["size"]
+    fd = rtmi.make_frame_data(w, h, sc, pose=rtmi.BENCH_POSE, rays_per_pixel=2, max_bounce=8)
+    pos, yaw, pitch = rtmi.BENCH_POSE
+    ofd = oracle.frame_data(w, h, pos=pos, yaw=yaw, pitch=pitch, rpp=2, max_bounce=8, scene=osc)
+    want = oracle.render(ofd, osc, 1, 3)
+    with rtmi.Renderer(w, h, variant=variant) as r:
+        r.upload_scene(sc)
+        assert r.acceleration() == rtmi.abi.ACCEL_NONE
+        r.enable_validation(True)
+        r.render_frames(fd, 1, 3)
+        got = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                   chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state(), counters=r.counters())
+    assert_same(got, want)
+    tri_hits = want["prim_id"][(want["prim_id"] != oracle.MISS_ID) & (want["prim_id"] >= ns)] - ns
+    assert len(tri_hits) > 300 and (tri_hits % 2 == 0).all()       # always the first copy
+    assert (tri_hits < 2 * nt).all()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_zero_bounces_and_many_samples(rtmi, oracle, variant):
     base = cases.CASES["c3_mesh_bench_pose"]
