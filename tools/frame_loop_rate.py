@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import raytracer_amd as R
 
 scene = R.reference_scene()
-for (w, h, rpp) in ((64, 36, 1), (64, 36, 4), (1280, 720, 1), (1280, 720, 4), (1920, 1080, 4)):
+for (w, h, rpp) in ((64, 36, 1), (64, 36, 4), (640, 360, 4), (1280, 720, 1), (1280, 720, 4), (1920, 1080, 4), (3840, 2160, 4)):
     fd = R.make_frame_data(w, h, scene, R.BENCH_POSE, rpp, 6)
     with R.Renderer(w, h) as r:
         r.upload_scene(scene)
