@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_bvh.hpp"
@@ -255,21 +257,62 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
                 boxes[i].margin_floor = (float)(std::fabs((double)spheres[i].radius) * 0.999999);
             }
             sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
-            tri_order.reserve(leaf_total);
-            std::vector<uint32_t> order;
-            for (uint32_t m = 0; m < nM; m++) {
-                const uint32_t start = (uint32_t)meshes[m].start_triangle, count = (uint32_t)meshes[m].num_triangles;
-                boxes.resize(count);
-                for (uint32_t k = 0; k < count; k++) {
-                    const rtmi_triangle &t = tris[start + k];
-                    for (int a = 0; a < 3; a++) {
-                        boxes[k].lo[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
-                        boxes[k].hi[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
+            std::vector<rtmi::PrimBox>().swap(boxes);
+            // The meshes' hierarchies do not depend on each other: a few threads build them side by
+            // side, each mesh into node and order vectors of its own, which are then appended in mesh
+            // order (node references moved), so the result does not depend on the thread count.
+            std::vector<uint32_t> leaf_base(nM + 1u, 0u);
+            for (uint32_t m = 0; m < nM; m++) leaf_base[m + 1] = leaf_base[m] + (uint32_t)meshes[m].num_triangles;
+            std::vector<std::vector<rtmi::BvhNode>> mesh_nodes(nM);
+            std::vector<std::vector<uint32_t>> mesh_order(nM);
+            auto build_meshes = [&](uint32_t first, uint32_t stride) {
+                std::vector<rtmi::PrimBox> tb;
+                for (uint32_t m = first; m < nM; m += stride) {
+                    const uint32_t start = (uint32_t)meshes[m].start_triangle, count = (uint32_t)meshes[m].num_triangles;
+                    tb.resize(count);
+                    for (uint32_t k = 0; k < count; k++) {
+                        const rtmi_triangle &t = tris[start + k];
+                        for (int a = 0; a < 3; a++) {
+                            tb[k].lo[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
+                            tb[k].hi[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
+                        }
+                        tb[k].margin_floor = 0.0f;
                     }
-                    boxes[k].margin_floor = 0.0f;
+                    mesh_root[m] = rtmi::BuildBvh(tb, mesh_nodes[m], mesh_order[m], leaf_base[m]);
+                    for (uint32_t k = 0; k < count; k++) mesh_order[m][k] += start;
                 }
-                mesh_root[m] = rtmi::BuildBvh(boxes, nodes, order, (uint32_t)tri_order.size());
-                for (uint32_t k = 0; k < count; k++) tri_order.push_back(start + order[k]);
+            };
+            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+            const uint32_t n_threads = (leaf_total < 32768u || nM < 2u) ? 1u : std::min({nM, hw, 8u});
+            if (n_threads == 1u) {
+                build_meshes(0u, 1u);
+            } else {
+                std::vector<std::thread> pool;
+                std::vector<std::exception_ptr> failed(n_threads);
+                for (uint32_t t = 0; t < n_threads; t++)
+                    pool.emplace_back([&, t] {
+                        try {
+                            build_meshes(t, n_threads);
+                        } catch (...) {
+                            failed[t] = std::current_exception();
+                        }
+                    });
+                for (std::thread &t : pool) t.join();
+                for (const std::exception_ptr &f : failed)
+                    if (f) std::rethrow_exception(f);
+            }
+            tri_order.reserve(leaf_total);
+            for (uint32_t m = 0; m < nM; m++) {
+                const uint32_t shift = (uint32_t)nodes.size();
+                for (rtmi::BvhNode &nd : mesh_nodes[m]) {
+                    if (!(nd.left & rtmi::kLeafFlag)) nd.left += shift;
+                    if (!(nd.right & rtmi::kLeafFlag)) nd.right += shift;
+                }
+                if (!(mesh_root[m] & rtmi::kLeafFlag)) mesh_root[m] += shift;  // kEmptyRef has the flag set
+                nodes.insert(nodes.end(), mesh_nodes[m].begin(), mesh_nodes[m].end());
+                tri_order.insert(tri_order.end(), mesh_order[m].begin(), mesh_order[m].end());
+                std::vector<rtmi::BvhNode>().swap(mesh_nodes[m]);
+                std::vector<uint32_t>().swap(mesh_order[m]);
             }
         } catch (const std::bad_alloc &) {
             return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation failed while building hierarchies");
