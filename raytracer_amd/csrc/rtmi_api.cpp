@@ -256,8 +256,20 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
                 }
                 boxes[i].margin_floor = (float)(std::fabs((double)spheres[i].radius) * 0.999999);
             }
-            sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
-            std::vector<rtmi::PrimBox>().swap(boxes);
+            // the sphere hierarchy on a thread of its own while the meshes are built below; its nodes
+            // are the first in the node array either way
+            std::exception_ptr sphere_failed;
+            std::thread sphere_builder([&] {
+                try {
+                    sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
+                } catch (...) {
+                    sphere_failed = std::current_exception();
+                }
+            });
+            struct Joiner {
+                std::thread &t;
+                ~Joiner() { if (t.joinable()) t.join(); }
+            } join_on_exit{sphere_builder};
             // The meshes' hierarchies do not depend on each other: a few threads build them side by
             // side, each mesh into node and order vectors of its own, which are then appended in mesh
             // order (node references moved), so the result does not depend on the thread count.
@@ -301,6 +313,8 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
                 for (const std::exception_ptr &f : failed)
                     if (f) std::rethrow_exception(f);
             }
+            sphere_builder.join();
+            if (sphere_failed) std::rethrow_exception(sphere_failed);
             tri_order.reserve(leaf_total);
             for (uint32_t m = 0; m < nM; m++) {
                 const uint32_t shift = (uint32_t)nodes.size();
