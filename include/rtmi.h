@@ -100,8 +100,8 @@ typedef enum rtmi_variant {
     RTMI_VARIANT_COMPACT    = 2,   /* the primary segment (identical for every sample of a pixel, RT.comp:449-453)
                                       is evaluated once per launch; pixels that see only sky are finished at once, the
                                       others are stream-compacted (wave ballot + prefix count) and traced by dense waves */
-    RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 12 paths per pixel
-                                      (frames x rays per pixel), REGENERATE otherwise (COMPACT spends about 0.4 ms
+    RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 8 paths per pixel
+                                      (frames x rays per pixel), REGENERATE otherwise (COMPACT spends about 0.15 ms
                                       per 1080p launch on classification, which a one-frame launch, the reference's
                                       own calling pattern, does not earn back); with a hierarchy, STREAM.
                                       While the uniform block (apart from frame_index) and the scene stay the same

@@ -617,8 +617,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_from_primary(const RenderPara
 // Variant 2, first kernel: evaluate every pixel's primary segment once.  A pixel whose primary ray
 // hits nothing gets the same radiance every frame (one sky evaluation, no random numbers), so it is
 // finished here with the frame-by-frame additions the shader would have made.  Pixels that hit are
-// appended to hit_list: the wave ballots its hit lanes, one lane reserves popcount slots with a single
-// atomic, and each hit lane takes the slot given by the count of hit lanes below it.
+// appended to hit_list: each wave ballots its hit lanes, the workgroup reserves the slots of all its
+// waves with a single atomic, and each hit lane takes the slot given by the count of hit lanes below it.
 // --------------------------------------------------------------------------------------------
 template <bool VALIDATE, bool BVH, bool STORE = false>
 __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p)
@@ -642,14 +642,25 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
         }
     }
 
+    // one reservation per workgroup: the four waves leave their counts in LDS, the first thread adds
+    // the total to the list's counter (the atomics on that one address are what limits this kernel)
+    // and every wave starts where the waves before it end
+    __shared__ uint32_t wave_hits[kBlockThreads / 64];
+    __shared__ uint32_t block_base;
     const unsigned long long mask = __ballot(hit);
-    if (mask != 0ull) {
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        uint32_t base = 0u;
-        if (lane == leader) base = atomicAdd(p.hit_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, (int)leader, 64);
-        if (hit) p.hit_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = s.y * p.width + s.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u) wave_hits[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < kBlockThreads / 64; w++) total += wave_hits[w];
+        block_base = total != 0u ? atomicAdd(p.hit_count, total) : 0u;
+    }
+    __syncthreads();
+    if (hit) {
+        uint32_t base = block_base;
+        for (uint32_t w = 0; w < wave; w++) base += wave_hits[w];
+        p.hit_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = s.y * p.width + s.x;
     }
 
     const bool sky_pixel = s.in_range && !hit;

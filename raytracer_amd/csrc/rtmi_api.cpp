@@ -515,7 +515,8 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     int variant = c->variant;
     RtCacheUse cache = RT_CACHE_NONE;
     if (variant == RTMI_VARIANT_AUTO) {
-        // measured at 1080p: REGENERATE is ahead up to 8 paths per pixel per launch, COMPACT from 16 on
+        // measured at 1080p (spheres scene, without stored hits): 4 paths per pixel per launch REGENERATE 0.30 ms
+        // against COMPACT's 0.34, 8 paths 0.54 against 0.48, 16 paths 1.01 against 0.76
         const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
         const bool compact_runs = fd->max_bounce_limit >= 2 && fd->rays_per_pixel >= 1;  // else the launcher falls back
         rtmi_frame_data key = *fd;
@@ -523,14 +524,14 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         const bool same_as_stored = c->cache_valid && c->cache_generation == c->scene_generation &&
                                     memcmp(&key, &c->cache_key, sizeof key) == 0;
         // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
-        // 12 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
+        // 8 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
         // 0.59; 2 paths: 0.23 against 0.20); below 8 the one-lane-per-pixel kernel starts from them.
         // With a hierarchy the pixel-streaming kernel is ahead at every launch size (10^6 + 10^6 primitive
         // scene at 1080p: 1 frame 11.4 ms against COMPACT's 27, 8 frames 80 against 93, 16 frames 158 against
         // 172, 64 frames 630 against 643); it starts from nothing stored.
         const bool stream = c->bvh_active;
         const bool use_store = compact_runs && !c->validate && !stream;
-        const bool compact = !stream && (c->bvh_active || paths_per_pixel >= (use_store ? 8u : 12u));
+        const bool compact = !stream && paths_per_pixel >= 8u;
         if (use_store) {
             const size_t np = n_pixels(c);
             if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
