@@ -26,7 +26,7 @@ for case in range(n_cases):
     yaw, pitch = float(rs.uniform(-180, 180)), float(rs.uniform(-80, 80))
     if rs.rand() < 0.5:
         pos, yaw, pitch = pose                      # the generator's own view of the scene
-    w, h = int(rs.choice([8, 23, 40, 64])), int(rs.choice([8, 17, 36]))
+    w, h = int(rs.choice([8, 23, 40, 64, 128])), int(rs.choice([8, 17, 36, 72]))
     rpp, mb = int(rs.choice([1, 1, 2, 3, 5])), int(rs.choice([0, 1, 2, 3, 6, 16]))
     first, n = int(rs.choice([1, 1, 2, 9])), int(rs.choice([1, 2, 5, 11]))
     accel = int(rs.choice([R.abi.ACCEL_NONE, R.abi.ACCEL_BVH]))
