@@ -222,8 +222,11 @@ __device__ __forceinline__ void bvh_sphere(BvhWalk &w, const DeviceScene &sc, ui
     const float b = 2.0f * dot(oc, d);
     const float c = dot(oc, oc) - g.w;
     const float disc = b * b - (4.0f * w.a) * c;
-    if (disc >= 0.0f) {
-        const float t = (-b - sqrtf(disc)) / (2.0f * w.a);
+    // with b >= 0 the root (-b - sqrt(disc)) / (2a) is not above zero (or not a number), which the
+    // shader's t > 0.0001 rejects: no need to evaluate it
+    if (disc >= 0.0f && b < 0.0f) {
+        const float root = sqrt_rn_admits(disc) ? sqrt_rn(disc) : sqrtf(disc);
+        const float t = (-b - root) / (2.0f * w.a);
         if (t > 0.0001f && t <= w.best.t) {
             // the shader's loop keeps the lowest index among equal t
             const uint32_t id = sc.bvh_sphere_id[e];
