@@ -68,16 +68,17 @@ struct BvhWalk {
 };
 
 // RayBox gates (Raytracing.comp:311-336, 352-356) of meshes base .. base + 63, exactly as the shader
-// evaluates them.  base may differ between lanes.
-template <bool COUNT>
+// evaluates them.  base may differ between lanes unless UNIFORM says it does not (the boxes then come
+// through scalar fetches).
+template <bool COUNT, bool UNIFORM = false>
 __device__ __forceinline__ unsigned long long bvh_gates(const DeviceScene &sc, uint32_t base, uint32_t n_meshes, V3 o, V3 inv,
                                                         Counters &cn)
 {
     unsigned long long gates = 0ull;
     const uint32_t chunk_end = (n_meshes - base < 64u) ? n_meshes : base + 64u;
     for (uint32_t m = base; m < chunk_end; m++) {
-        const float4 lo = sc.mesh_box[2 * m + 0];
-        const float4 hi = sc.mesh_box[2 * m + 1];
+        const float4 lo = UNIFORM ? ld_uniform(sc.mesh_box, 2 * m + 0) : sc.mesh_box[2 * m + 0];
+        const float4 hi = UNIFORM ? ld_uniform(sc.mesh_box, 2 * m + 1) : sc.mesh_box[2 * m + 1];
         const float t1 = (lo.x - o.x) * inv.x;
         const float t2 = (hi.x - o.x) * inv.x;
         const float t3 = (lo.y - o.y) * inv.y;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void bvh_begin(BvhWalk &w, const DeviceScene &sc, uin
     w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     w.a = dot(d, d);
     w.gate_base = 0u;
-    w.gates = bvh_gates<COUNT>(sc, 0u, n_meshes, o, w.inv, cn);
+    w.gates = bvh_gates<COUNT, true>(sc, 0u, n_meshes, o, w.inv, cn);
     w.cur_mesh = 0u;
     w.leaf_pos = 0u;
     w.leaf_left = 0u;
