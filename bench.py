@@ -26,9 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
+# 256 CU x 4 SIMD x 32 lanes per cycle x 2 flops (one v_fma_f32 per wave64 every 2 cycles) x 2.4 GHz.
+# The arithmetic contract rounds every multiply and add separately, so an instruction carries one flop:
+# the ceiling of this contract is half the peak (78.6), 69.9 at the 2.25 cycles per instruction that
+# v_mul_f32 / v_add_f32 were measured to issue at on the box (tools/ubench).
+FP32_VECTOR_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-FP32_UNFUSED_PEAK_TFLOPS = 69.9    # 1024 SIMDs x 64 lanes x 2.4 GHz / 2.25 cycles, one flop per instruction
+FP32_UNFUSED_PEAK_TFLOPS = 78.6
+FP32_UNFUSED_MEASURED_TFLOPS = 69.9
 
 WORKLOADS = {
     # name: (scene, width, height, max_bounce)
@@ -94,6 +99,28 @@ def cpu_baseline(workload, frames_hint, budget_s):
     }
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU) and pass on rank 0's JSON line and their exit code.  This
+    process never touches a GPU (torch.cuda.device_count() does not initialise one)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("RTMI_BENCH_REHEARSE") != "1":
+        sys.stderr.write("bench.py: --gpus %d asked for, but only %d device%s visible on this machine\n" % (
+            n_gpus, have, " is" if have == 1 else "s are"))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +133,12 @@ def main():
                          "4 pixel-streaming kernel (hierarchy scenes; default for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--reduce", default="reduce", choices=["reduce", "allreduce"],
+                    help="N > 1: sum the images onto rank 0 only (default; the only rank that resolves and would "
+                         "dump the picture) or onto every rank")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -117,11 +149,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                     "--nproc-per-node %d ..." % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the library has no CPU fallback")
     # Rehearsal aid for a one-GPU box: RTMI_BENCH_REHEARSE=1 puts every rank on GPU 0 and swaps RCCL
@@ -149,9 +177,11 @@ def main():
     renderer.upload_scene(scene)
     sr = ShardedRenderer(renderer, device)
 
+    dst = 0 if args.reduce == "reduce" else None
+
     def step():
-        sr.render(fd, total_frames)
-        if world > 1:
+        sr.render(fd, total_frames, dst=dst)
+        if world > 1 and (dst is None or rank == dst):
             sr.resolve(total_frames)
 
     # algorithmic work of this rank's launch, from exact event counters (instrumented kernel, untimed)
@@ -160,8 +190,22 @@ def main():
     renderer.reset_counters()
     renderer.render_frames(fd, first, frames)
     counters = renderer.counters()
-    renderer.enable_validation(False)
     flops_per_launch = R.algorithmic_flops(counters)
+    # What the kernels execute is less than what the algorithm specifies: the shader casts the same primary
+    # ray for every sample of a pixel, and variants 2 and 4 evaluate that segment once per pixel and launch
+    # (variant 2 also the ray set-up, and the sky term of pixels that see only sky).  The events of one
+    # primary segment per pixel are those of a one-frame, one-sample, one-bounce launch.
+    fd1 = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=1)
+    renderer.reset_counters()
+    renderer.render_frames(fd1, first, 1)
+    primary = renderer.counters()
+    renderer.enable_validation(False)
+    hoisted_per_repeat = R.algorithmic_flops({k: (primary[k] if k in ("n_sphere_tests", "n_sphere_disc_ge0", "n_box_tests", "n_tri_tests")
+                                                  else 0) for k in primary})
+    if args.variant == 2:
+        hoisted_per_repeat += 74 * width * height + 63 * primary["n_env_evals"]
+    repeats_saved = frames * fd.rays_per_pixel - 1 if args.variant in (2, 4) else 0
+    flops_executed = flops_per_launch - repeats_saved * hoisted_per_repeat
 
     for _ in range(args.warmup):
         step()
@@ -189,6 +233,7 @@ def main():
     value = paths_per_step * args.steps / elapsed / 1e6
     kernel_ms = kernel_ms_total / max(1, launches)
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+    executed_tflops = flops_executed / (kernel_ms * 1e-3) / 1e12
     algorithmic_bytes = width * height * (16 + 4 + (0 if first == 1 else 16))   # accum write (+read) + rgba8
     # HBM bytes per launch from the PMC passes kept under profiles/ (only valid for the configuration
     # they were collected on)
@@ -212,7 +257,8 @@ def main():
             "closest_hit": "hierarchy" if renderer.acceleration() == R.abi.ACCEL_BVH else "exhaustive loops",
             "variant": {0: "megakernel", 1: "regenerate", 2: "compact", 4: "stream"}[args.variant],
             "frames_per_gpu": frames, "total_frames": total_frames,
-            "parallelism": "frame-range split x%d + RCCL all-reduce(sum) of float4 accumulation" % world if world > 1 else "single GPU",
+            "parallelism": "frame-range split x%d + RCCL %s(sum) of float4 accumulation" % (
+                world, "reduce to rank 0" if dst is not None else "all-reduce") if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "fp32_valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -222,12 +268,19 @@ def main():
             "algorithmic_flops_per_launch": flops_per_launch,
             "algorithmic_hbm_bytes_per_launch": algorithmic_bytes,
             "hbm_gbs_algorithmic": algorithmic_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
-            # measured on the box (tools/ubench): an unpacked, unfused FP32 instruction with vector-register
-            # operands issues every 2.25 cycles per SIMD; 157.3 needs packed FMA (4 flops per lane per instruction)
-            "peak_unfused_unpacked": FP32_UNFUSED_PEAK_TFLOPS,
-            "frac_of_unfused_peak": achieved_tflops / FP32_UNFUSED_PEAK_TFLOPS,
-            "note": "arithmetic contract rounds every multiply and add separately (no FMA, nothing to pack): "
-                    "the reachable ceiling is peak_unfused_unpacked",
+            # algorithmic = the reference algorithm's events (every path walks its primary segment);
+            # executed = the same minus the primary segments, ray set-ups and sky terms that are evaluated once per
+            # pixel and launch instead of once per path
+            "executed_flops_per_launch": flops_executed,
+            "achieved_executed": executed_tflops,
+            "frac_executed": executed_tflops / FP32_VECTOR_PEAK_TFLOPS,
+            # one flop per instruction (no FMA) halves the peak; 69.9 with the measured 2.25 cycles per v_mul / v_add
+            "peak_unfused": FP32_UNFUSED_PEAK_TFLOPS,
+            "peak_unfused_measured_issue": FP32_UNFUSED_MEASURED_TFLOPS,
+            "frac_executed_of_unfused_peak": executed_tflops / FP32_UNFUSED_PEAK_TFLOPS,
+            "note": "peak = one v_fma_f32 per wave64 per 2 cycles per SIMD; the arithmetic contract rounds every multiply and "
+                    "add separately (no FMA), so its ceiling is peak_unfused; frac prices the reference algorithm's flops, "
+                    "frac_executed the flops the kernels actually perform",
         },
         "kernel_mpaths_per_s": width * height * frames / (kernel_ms * 1e-3) / 1e6,
         "msegments_per_s": counters["n_segments"] / (kernel_ms * 1e-3) / 1e6,
@@ -243,14 +296,22 @@ def main():
         mesh_gates = counters["n_segments"] * fd.mesh_number
         node_visits = (counters["n_box_tests"] - mesh_gates) // 2
         gather_bytes = node_visits * 64 + counters["n_sphere_tests"] * 20 + counters["n_tri_tests"] * 68 + algorithmic_bytes
-        gbs = gather_bytes / (kernel_ms * 1e-3) / 1e9
+        gather_gbs = gather_bytes / (kernel_ms * 1e-3) / 1e9
+        # headline: the bytes the PMC counters saw reach the memory side (profiles/traffic_*.json, collected on
+        # this configuration) over this run's launch time; the gather bytes, most of which L2 and Infinity Cache
+        # serve, are a secondary figure.  Without a counter file for this configuration only the latter exists.
+        measured_gbs = traffic / (kernel_ms * 1e-3) / 1e9 if traffic is not None else None
+        gbs = measured_gbs if measured_gbs is not None else gather_gbs
         result["roofline"].update({
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "algorithmic_gather_bytes_per_launch": gather_bytes, "node_visits_per_launch": node_visits,
+            "achieved_is": "measured HBM traffic (PMC) / kernel time" if measured_gbs is not None else
+                           "algorithmic gather bytes / kernel time (no PMC traffic file for this configuration)",
+            "algorithmic_gather_bytes_per_launch": gather_bytes, "gather_gbs": gather_gbs,
+            "gather_frac_of_hbm_peak": gather_gbs / HBM_PEAK_GBS, "node_visits_per_launch": node_visits,
             "fp32_tflops_algorithmic": achieved_tflops,
-            "note": "hierarchy traversal: algorithmic bytes are the node and primitive records the walk fetches "
-                    "(most are served by L2 / Infinity Cache: compare hbm_gbs_from_traffic, the part that "
-                    "reaches the memory side, so achieved / peak overstates how close the kernel is to the HBM limit)",
+            "note": "hierarchy traversal: a chain of dependent 64-byte gathers, bound by memory latency and instruction "
+                    "issue rather than by HBM bandwidth; frac is the measured share of the HBM peak, gather_* price the "
+                    "node and primitive records the walk fetches wherever they are served from",
         })
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds)

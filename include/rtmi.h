@@ -119,7 +119,7 @@ typedef enum rtmi_variant {
  * the primitives near the ray get the shader's tests.  The hit returned is the same: the tests are
  * the shader's own, the box tests carry margins for their rounding, and ties keep the shader's loop
  * order.  RTMI_ACCEL_AUTO builds hierarchies when the scene holds more than 256 primitives.  The
- * reference has no counterpart (its scenes hold 5 spheres and 12 triangles, main.cpp:125-164). */
+ * reference has no counterpart (its scene holds 1 sphere and 14 triangles in 2 meshes, main.cpp:161-185). */
 typedef enum rtmi_accel {
     RTMI_ACCEL_AUTO = 0,
     RTMI_ACCEL_NONE = 1,
@@ -204,7 +204,8 @@ RTMI_API int rtmi_checkpoint_load(rtmi_ctx *ctx, const char *path, uint32_t *fra
  * shader has no counterpart; in Vulkan terms this is rebinding descriptor 5. */
 RTMI_API int rtmi_bind_accum(rtmi_ctx *ctx, void *device_float4);
 RTMI_API void *rtmi_accum_device_ptr(rtmi_ctx *ctx);
-/* Launch on a caller-owned hipStream_t (NULL returns to the context's own stream). */
+/* Launch on a caller-owned hipStream_t.  NULL returns to the context's own (non-blocking) stream; it
+ * does NOT mean HIP's null stream, which is named by the runtime's hipStreamLegacy handle. */
 RTMI_API int rtmi_set_stream(rtmi_ctx *ctx, void *hip_stream);
 RTMI_API int rtmi_synchronize(rtmi_ctx *ctx);
 /* Device time of the most recent render call, from HIP events recorded around its kernels on the

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <exception>
 #include <numeric>
+#include <system_error>
 #include <thread>
 
 namespace rtmi {
@@ -182,20 +183,27 @@ struct Builder {
             std::vector<BvhNode> right_nodes;
             right_nodes.reserve(e - mid);  // more than it can need; reserved here so that the worker never allocates
             std::exception_ptr failure;
-            std::thread worker([&] {
-                try {
-                    r = Range(mid, e, levels - 1, right_nodes, fork - 1);
-                } catch (...) {
-                    failure = std::current_exception();
-                }
-            });
+            std::thread worker;
+            bool forked = true;
+            try {
+                worker = std::thread([&] {
+                    try {
+                        r = Range(mid, e, levels - 1, right_nodes, fork - 1);
+                    } catch (...) {
+                        failure = std::current_exception();
+                    }
+                });
+            } catch (const std::system_error &) {
+                forked = false;  // no thread to be had: this one builds both halves, into the same two vectors
+            }
             try {
                 l = Range(b, mid, levels - 1, nodes, fork - 1);
+                if (!forked) r = Range(mid, e, levels - 1, right_nodes, 0);
             } catch (...) {
-                worker.join();
+                if (forked) worker.join();
                 throw;
             }
-            worker.join();
+            if (forked) worker.join();
             if (failure) std::rethrow_exception(failure);
             const uint32_t shift = (uint32_t)nodes.size();
             for (BvhNode &nd : right_nodes) {

@@ -186,6 +186,12 @@ bool LoadSnapshot(const char *path, Snapshot &snap)
     if (std::fread(head, 4, 4, in.f) != 4) return false;
     if (head[0] == 0 || head[1] == 0 || (uint64_t)head[0] * head[1] > 0x7FFFFFFFull) return false;
     const size_t n = (size_t)head[0] * head[1] * 4;
+    // the header is not trusted: the file must hold exactly the payload it announces before anything
+    // of that size is allocated
+    if (std::fseek(in.f, 0, SEEK_END) != 0) return false;
+    const long long file_bytes = (long long)std::ftell(in.f);
+    if (file_bytes < 0 || (unsigned long long)file_bytes != 24ull + (unsigned long long)n * sizeof(float)) return false;
+    if (std::fseek(in.f, 24, SEEK_SET) != 0) return false;
     std::vector<float> data(n);
     if (std::fread(data.data(), sizeof(float), n, in.f) != n) return false;
     if (std::fgetc(in.f) != EOF) return false;  // trailing bytes: not a snapshot of this extent

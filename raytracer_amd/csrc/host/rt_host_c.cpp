@@ -154,6 +154,8 @@ int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nod
         return (int)nodes.size();
     } catch (const std::bad_alloc &) {
         return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_UNSUPPORTED;
     }
 }
 
@@ -169,6 +171,8 @@ int rtmi_scene_save(const char *path, const rtmi_sphere *spheres, uint32_t n_sph
         return rtmi::SaveScene(path, sc) ? RTMI_OK : RTMI_ERR_IO;
     } catch (const std::bad_alloc &) {
         return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_IO;
     }
 }
 
@@ -194,6 +198,8 @@ int rtmi_scene_load(const char *path, rtmi_sphere *spheres, uint32_t *n_spheres,
         return RTMI_OK;
     } catch (const std::bad_alloc &) {
         return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_IO;
     }
 }
 

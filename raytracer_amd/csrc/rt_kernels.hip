@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
 // samples of a pixel stay in one lane, in the shader's order), walks are resumable as in k_paths
 // (all walking lanes step until half of them are done, the finished ones shade and start their next
 // ray), and the only idle lanes are those at the very end of the launch.  Pixels are handed out in
-// 8 x 8 tiles.  p.hit_count is the cursor and must be zero at launch.
+// 8 x 8 tiles.  p.stream_cursor is the cursor and must be zero at launch.
 // --------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 64;
 #ifndef RT_STREAM_MIN_WAVES
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
         if (need != 0ull && !exhausted) {
             const uint32_t want = (uint32_t)__popcll(need);
             uint32_t first = 0u;
-            if (lane == 0u) first = atomicAdd(p.hit_count, want);
+            if (lane == 0u) first = atomicAdd(p.stream_cursor, want);
             first = (uint32_t)__shfl((int)first, 0, 64);
             exhausted = first + want >= n_items || first + want < first;
             const uint32_t item = first + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
@@ -850,7 +850,7 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     const bool bvh = p.use_bvh != 0u;
     // the streaming kernel exists for hierarchy scenes only, and its 32-bit cursor counts whole 8 x 8 tiles
     const uint64_t stream_items = (uint64_t)((p.width + 7u) / 8u) * ((p.height + 7u) / 8u) * 64u;
-    if (variant == 4 && (!bvh || !p.hit_count || stream_items > 0xF0000000ull)) variant = 1;
+    if (variant == 4 && (!bvh || !p.stream_cursor || stream_items > 0xF0000000ull)) variant = 1;
     if (variant == 2 && (p.max_bounce < 2 || p.rays_per_pixel == 0)) variant = 1;
     if ((variant == 1 || variant == 4) && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
 #define RT_LAUNCH(KERNEL, GRID, BLOCK)                                                                    \
@@ -908,12 +908,14 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
 #undef RT_LAUNCH
     } else if (variant == 4) {
         if (cache != RT_CACHE_NONE) return hipErrorInvalidValue;
-        hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
+        hipError_t e = hipMemsetAsync(p.stream_cursor, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         // as many single-wave workgroups as the device keeps resident (more would only queue up)
-        int device = 0, cus = 0;
-        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+        int device = 0, cus = (int)p.n_cus;
+        if (cus == 0) {
+            if ((e = hipGetDevice(&device)) != hipSuccess) return e;
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+        }
         const uint32_t n_tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
         const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * kStreamWavesPerCu;
         const dim3 grid_stream(n_tiles < resident ? n_tiles : resident, 1, 1);

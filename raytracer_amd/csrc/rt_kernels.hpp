@@ -33,6 +33,9 @@ struct RenderParams {
     unsigned long long *counters;  // validation only, 16 entries
     uint32_t *hit_list;     // variant 2: pixels whose primary ray hits something, compacted
     uint32_t *hit_count;    // variant 2: length of hit_list, zeroed before every launch that builds the list
+    uint32_t *stream_cursor;  // variant 4: next pixel item to hand out, zeroed before every launch (a word of its own:
+                              // a stored work list keeps hit_count alive between launches)
+    uint32_t n_cus;         // compute units of the device (variant 4 sizes its grid by it); 0 = ask the runtime
     // Primary-segment cache (variant 2, static camera): per pixel {t, u, v, bits(prim)} of the primary
     // hit, or {r, g, b, bits(miss id)} = the radiance a sky pixel adds per frame, and the material row.
     float4 *primary;

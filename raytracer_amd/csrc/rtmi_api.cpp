@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -49,7 +50,8 @@ struct rtmi_ctx {
     float4 *accum = nullptr;
     uint32_t *out_rgba8 = nullptr;
     uint32_t *hit_ids = nullptr, *chain_hash = nullptr, *rng_state = nullptr;
-    uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list
+    uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list; hit_count[16] is variant 4's cursor
+    int n_cus = 0;
     // Primary-segment cache (RTMI_VARIANT_AUTO only).  With an unchanged camera, scene and frame
     // constants every launch would classify the same pixels and find the same primary hits; they are
     // stored once (with the work list) and later launches start from them.  The key is the whole
@@ -157,6 +159,7 @@ int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out)
         return code;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -259,13 +262,18 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
             // the sphere hierarchy on a thread of its own while the meshes are built below; its nodes
             // are the first in the node array either way
             std::exception_ptr sphere_failed;
-            std::thread sphere_builder([&] {
-                try {
-                    sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
-                } catch (...) {
-                    sphere_failed = std::current_exception();
-                }
-            });
+            std::thread sphere_builder;
+            try {
+                sphere_builder = std::thread([&] {
+                    try {
+                        sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
+                    } catch (...) {
+                        sphere_failed = std::current_exception();
+                    }
+                });
+            } catch (const std::system_error &) {
+                sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);  // no thread to be had: build it here
+            }
             struct Joiner {
                 std::thread &t;
                 ~Joiner() { if (t.joinable()) t.join(); }
@@ -301,19 +309,33 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
             } else {
                 std::vector<std::thread> pool;
                 std::vector<std::exception_ptr> failed(n_threads);
-                for (uint32_t t = 0; t < n_threads; t++)
-                    pool.emplace_back([&, t] {
-                        try {
-                            build_meshes(t, n_threads);
-                        } catch (...) {
-                            failed[t] = std::current_exception();
-                        }
-                    });
+                std::vector<uint32_t> not_started;
+                for (uint32_t t = 0; t < n_threads; t++) {
+                    try {
+                        pool.emplace_back([&, t] {
+                            try {
+                                build_meshes(t, n_threads);
+                            } catch (...) {
+                                failed[t] = std::current_exception();
+                            }
+                        });
+                    } catch (const std::system_error &) {
+                        not_started.push_back(t);
+                    }
+                }
+                // shares whose thread could not be created are built here; the result is the same
+                std::exception_ptr here;
+                try {
+                    for (uint32_t t : not_started) build_meshes(t, n_threads);
+                } catch (...) {
+                    here = std::current_exception();
+                }
                 for (std::thread &t : pool) t.join();
+                if (here) std::rethrow_exception(here);
                 for (const std::exception_ptr &f : failed)
                     if (f) std::rethrow_exception(f);
             }
-            sphere_builder.join();
+            if (sphere_builder.joinable()) sphere_builder.join();
             if (sphere_failed) std::rethrow_exception(sphere_failed);
             tri_order.reserve(leaf_total);
             for (uint32_t m = 0; m < nM; m++) {
@@ -330,6 +352,11 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
             }
         } catch (const std::bad_alloc &) {
             return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation failed while building hierarchies");
+        } catch (const std::exception &ex) {
+            // e.g. std::system_error from thread creation
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: building hierarchies failed: %s", ex.what());
+        } catch (...) {
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: building hierarchies failed");
         }
         off_nodes = align_up(total, 256);
         off_bsph = align_up(off_nodes + nodes.size() * sizeof(rtmi::BvhNode), 256);
@@ -462,6 +489,7 @@ static int ensure_validation_buffers(rtmi_ctx *c)
 
 int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames)
 {
+    constexpr bool no_alloc = false;
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     if (!fd) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: frame data is NULL");
     if (!c->has_scene) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_render: no scene uploaded");
@@ -508,19 +536,22 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.hit_ids = c->hit_ids;
     p.hit_list = c->hit_list;
     p.hit_count = c->hit_count;
+    p.stream_cursor = p.hit_count + 16;
+    p.n_cus = (uint32_t)c->n_cus;
     p.chain_hash = c->chain_hash;
     p.rng_state = c->rng_state;
     p.counters = c->counters;
 
     int variant = c->variant;
     RtCacheUse cache = RT_CACHE_NONE;
+    bool store_has_list = false;
+    rtmi_frame_data key = *fd;
+    key.frame_index = 0;
     if (variant == RTMI_VARIANT_AUTO) {
         // measured at 1080p (spheres scene, without stored hits): 4 paths per pixel per launch REGENERATE 0.30 ms
         // against COMPACT's 0.34, 8 paths 0.54 against 0.48, 16 paths 1.01 against 0.76
         const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
         const bool compact_runs = fd->max_bounce_limit >= 2 && fd->rays_per_pixel >= 1;  // else the launcher falls back
-        rtmi_frame_data key = *fd;
-        key.frame_index = 0;
         const bool same_as_stored = c->cache_valid && c->cache_generation == c->scene_generation &&
                                     memcmp(&key, &c->cache_key, sizeof key) == 0;
         // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
@@ -530,7 +561,7 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // scene at 1080p: 1 frame 11.4 ms against COMPACT's 27, 8 frames 80 against 93, 16 frames 158 against
         // 172, 64 frames 630 against 643); it starts from nothing stored.
         const bool stream = c->bvh_active;
-        const bool use_store = compact_runs && !c->validate && !stream;
+        const bool use_store = compact_runs && !c->validate && !stream && !no_alloc;
         const bool compact = !stream && paths_per_pixel >= 8u;
         if (use_store) {
             const size_t np = n_pixels(c);
@@ -538,21 +569,20 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
             if (!c->primary_mat) HIP_TRY(c, hipMalloc(&c->primary_mat, np * sizeof(uint32_t)));
             // the work list is only needed (and only built) by COMPACT
             cache = (same_as_stored && (!compact || c->cache_has_list)) ? RT_CACHE_LOAD : RT_CACHE_STORE;
+            store_has_list = compact;
         }
         variant = stream ? RTMI_VARIANT_STREAM : compact ? RTMI_VARIANT_COMPACT : RTMI_VARIANT_REGENERATE;
-        if (cache == RT_CACHE_STORE) {
-            c->cache_key = key;
-            c->cache_generation = c->scene_generation;
-            c->cache_valid = true;
-            c->cache_has_list = compact;
-        }
     }
-    // any other launch of the classifying kernel rebuilds the work list for its own camera
-    if (variant == RTMI_VARIANT_COMPACT && cache == RT_CACHE_NONE) c->cache_has_list = false;
+    // A launch that (re)writes the stored primary segments or the context's work list makes what was
+    // stored unusable until it has been enqueued successfully; so does a failure of any kind below.
+    const bool rewrites_store = cache == RT_CACHE_STORE || (variant == RTMI_VARIANT_COMPACT && cache == RT_CACHE_NONE && !no_alloc);
+    if (cache == RT_CACHE_STORE) c->cache_valid = false;
+    if (rewrites_store) c->cache_has_list = false;
     p.primary = c->primary;
     p.primary_mat = c->primary_mat;
     hipEvent_t ev0 = c->ev_start, ev1 = c->ev_stop;
-    if (c->ev_logging) {
+    const bool events = !no_alloc;   // hipEventCreate may allocate
+    if (events && c->ev_logging) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             HIP_TRY(c, hipEventCreate(&a));
@@ -563,11 +593,38 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         ev1 = c->ev_pool[c->ev_used].second;
         c->ev_used++;
     }
-    HIP_TRY(c, hipEventRecord(ev0, c->stream));
+    auto drop_store = [&]() {
+        c->cache_valid = false;
+        c->cache_has_list = false;
+    };
+    if (events) {
+        hipError_t er = hipEventRecord(ev0, c->stream);
+        if (er != hipSuccess) {
+            drop_store();
+            return fail(c, RTMI_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
+        }
+    }
     hipError_t e = rt_launch_render(variant, c->validate, p, c->stream, cache);
-    if (e != hipSuccess) return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
-    HIP_TRY(c, hipEventRecord(ev1, c->stream));
-    c->timed = !c->ev_logging;
+    if (e != hipSuccess) {
+        drop_store();
+        return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
+    }
+    if (events) {
+        hipError_t er = hipEventRecord(ev1, c->stream);
+        if (er != hipSuccess) {
+            drop_store();
+            return fail(c, RTMI_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
+        }
+    }
+    if (cache == RT_CACHE_STORE) {
+        // stored by the launch just enqueued, on c->stream (rtmi_set_stream drops the store: a launch on
+        // another stream would not be ordered after this one)
+        c->cache_key = key;
+        c->cache_generation = c->scene_generation;
+        c->cache_valid = true;
+        c->cache_has_list = store_has_list;
+    }
+    c->timed = events && !c->ev_logging;
     return RTMI_OK;
 }
 
@@ -707,6 +764,7 @@ int rtmi_bind_accum(rtmi_ctx *c, void *device_float4)
     if (device_float4 && (reinterpret_cast<uintptr_t>(device_float4) & 15u))
         return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_bind_accum: pointer must be 16-byte aligned");
     c->accum = device_float4 ? static_cast<float4 *>(device_float4) : c->own_accum;
+    c->cache_valid = c->cache_has_list = false;
     return RTMI_OK;
 }
 
@@ -717,6 +775,8 @@ int rtmi_set_stream(rtmi_ctx *c, void *hip_stream)
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     c->timed = false;
+    // what an earlier launch stored was written on the previous stream; nothing orders this one after it
+    c->cache_valid = c->cache_has_list = false;
     return RTMI_OK;
 }
 
@@ -767,6 +827,7 @@ int rtmi_enable_validation(rtmi_ctx *c, int on)
 {
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     c->validate = on != 0;
+    c->cache_valid = c->cache_has_list = false;
     if (c->validate) {
         if (int rc = use_device(c)) return rc;
         return ensure_validation_buffers(c);
@@ -861,6 +922,9 @@ int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh
     int rc = RTMI_OK;
     // one allocation: origins | directions | t | prim
     hipError_t e = hipMalloc(&dbuf, n * 8 * sizeof(float));
+    if (e != hipSuccess || !dbuf)
+        return fail(c, e == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP, "rtmi_selftest_closest_hit: hipMalloc: %s",
+                    hipGetErrorString(e));
     float *d_o = dbuf, *d_d = dbuf + 3 * n, *d_t = dbuf + 6 * n;
     uint32_t *d_p = reinterpret_cast<uint32_t *>(dbuf + 7 * n);
     if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);

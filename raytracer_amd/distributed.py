@@ -50,20 +50,45 @@ def render_sharded(render_range, accum, total_frames, first_frame=1, group=None,
 
 class ShardedRenderer:
     """A Renderer bound to a torch tensor so that torch.distributed can reduce the accumulation
-    image in place; kernels are launched on torch's current stream so the collective is ordered
-    after them without a host synchronisation."""
+    image in place.
+
+    Everything that touches the image (clearing it, the render kernels, the collective, the resolve
+    kernel) is enqueued on ONE torch stream owned by this object, whose non-zero handle the library
+    launches on (rtmi_set_stream treats a NULL handle as "the context's own stream", so torch's
+    default stream, handle 0, cannot be named that way).  The stream is joined to the caller's
+    current stream on entry and exit, so the whole sequence is ordered by the device alone, without
+    a host synchronisation."""
 
     def __init__(self, renderer, device):
         self.renderer = renderer
         self.device = torch.device(device)
         self.accum = torch.zeros((renderer.height, renderer.width, 4), dtype=torch.float32, device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        assert self.stream.cuda_stream != 0
+        # the zero fill above ran on the caller's stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         renderer.bind_accum(self.accum.data_ptr())
-        renderer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        renderer.set_stream(self.stream.cuda_stream)
 
     def render(self, fd, total_frames, first_frame=1, group=None, dst=None):
-        rng = render_sharded(lambda first, n: self.renderer.render_frames(fd, first, n), self.accum,
-                             total_frames, first_frame, group, dst)
+        """This rank's share of the frames + the sum over ranks (all ranks, or rank dst only)."""
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            rng = render_sharded(lambda first, n: self.renderer.render_frames(fd, first, n), self.accum,
+                                 total_frames, first_frame, group, dst)
+        caller.wait_stream(self.stream)
         return rng
 
     def resolve(self, total_frames):
-        self.renderer.resolve_output(total_frames)
+        """Alpha back to 1 and the display image = sum / total_frames (on the rank(s) holding the sum)."""
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        self.renderer.resolve_output(total_frames)   # launches on self.stream
+        caller.wait_stream(self.stream)
+
+    def close(self):
+        """Give the renderer back its own image and stream."""
+        self.renderer.synchronize()
+        self.renderer.bind_accum(None)
+        self.renderer.set_stream(None)

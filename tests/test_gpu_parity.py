@@ -294,11 +294,9 @@ def test_external_buffer_and_stream(rtmi):
         first, n = sr.render(fd, 8)
         assert (first, n) == (1, 8)
         sr.resolve(8)
-        torch.cuda.synchronize(dev)
-        got = sr.accum.cpu().numpy()
+        got = sr.accum.cpu().numpy()      # on torch's current stream, which render() / resolve() joined: no device-wide wait
         out = r.read_output_rgba8()
-        r.bind_accum(None)
-        r.set_stream(None)
+        sr.close()
     want = cases.load_golden("c3_mesh_bench_pose")
     assert cases.bits_equal(got, want["accum"]) and np.array_equal(out, want["rgba8"])
 
@@ -358,6 +356,85 @@ def test_full_size_split_invariance_256_frames(rtmi):
     assert np.isfinite(one).all() and (one[..., 3] == 1.0).all()
     mean = one[..., :3] / 256.0
     assert 0.2 < mean.mean() < 2.0
+
+
+def test_full_size_mesh_scene_256_frames(rtmi):
+    """Config C3 at its stated length (reference scene, 1080p, 256 frames, depth 8): one launch == four
+    launches of 64 frames == the one-lane-per-pixel kernel, bit for bit.  256 frames take the wave-shared
+    triangle tests through the 8-frame ring 32 times over."""
+    case = dict(FULL, scene="reference", pose=cases.BENCH_POSE)
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    with rtmi.Renderer(1920, 1080, variant=2) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 256)
+        one = r.read_accum()
+        out_one = r.read_output_rgba8()
+        for k in range(4):
+            r.render_frames(fd, 1 + 64 * k, 64)
+        four = r.read_accum()
+        assert np.array_equal(one.view(np.uint32), four.view(np.uint32)) and np.array_equal(out_one, r.read_output_rgba8())
+        r.set_variant(1)
+        r.render_frames(fd, 1, 256)
+        same = np.array_equal(one.view(np.uint32), r.read_accum().view(np.uint32))
+        assert same, "variant 1 differs from variant 2"
+        r.set_variant(3)                  # chosen per launch, primary segments kept between the two launches
+        r.render_frames(fd, 1, 128)
+        r.render_frames(fd, 129, 128)
+        same = np.array_equal(one.view(np.uint32), r.read_accum().view(np.uint32))
+        assert same, "two launches under variant 3 differ from one launch of variant 2"
+    assert np.isfinite(one).all() and (one[..., 3] == 1.0).all()
+    assert 0.2 < (one[..., :3] / 256.0).mean() < 2.0
+
+
+def test_4k_last_rank_frame_range(rtmi, oracle):
+    """Config C4's image (reference scene, 3840x2160, depth 8) on the frame range its eighth rank starts
+    with (frames 3585..3588 of 4096): the float part of the seed (Raytracing.comp:462) reaches
+    3839 + 3840 * 2159 = 8 294 399 (exact in binary32, close to 2^23) and the frame term wraps in uint32.
+    Variant 2 against variants 0 and 1 bit for bit, four whole rows against the oracle, counter identities."""
+    w, h, first, n = 3840, 2160, 3585, 4
+    case = dict(scene="reference", pose=cases.BENCH_POSE, size=(w, h), rpp=1, max_bounce=8, first=first, n=n)
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    got = {}
+    with rtmi.Renderer(w, h, variant=2) as r:
+        r.upload_scene(sc)
+        r.enable_validation(True)
+        for variant in (2, 0, 1):
+            r.set_variant(variant)
+            r.clear_accum()
+            r.reset_counters()
+            r.render_frames(fd, first, n)
+            cur = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                       chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state(), counters=r.counters())
+            if variant == 2:
+                got = cur
+                continue
+            for k in ("accum", "rgba8", "prim_id", "chain_hash", "rng_state"):
+                same = np.array_equal(got[k].view(np.uint32) if k == "accum" else got[k],
+                                      cur[k].view(np.uint32) if k == "accum" else cur[k])
+                assert same, "variant %d differs from variant 2 in %s" % (variant, k)
+            assert cur["counters"] == got["counters"]
+            del cur
+    osc = cases.oracle_scene(case)
+    ofd = cases.oracle_frame_data(case, osc)
+    for y0 in (0, 700, 1079, 2159):
+        want = oracle.render(ofd, osc, first, n, rows=(y0, y0 + 1))
+        for k in ("accum", "rgba8", "prim_id", "chain_hash", "rng_state"):
+            same = np.array_equal(got[k][y0].view(np.uint32) if k == "accum" else got[k][y0],
+                                  want[k][y0].view(np.uint32) if k == "accum" else want[k][y0])
+            assert same, (k, y0)
+        del want
+    # the seed of the last pixel, frame 3588: uint(3839 + 3840 * 2159) + 3588 * 719393 (mod 2^32), advanced by the
+    # path's random numbers; its frame-start value is what the oracle row above already pins, here the formula itself
+    assert float(np.float32(3839.0) + np.float32(3840.0) * np.float32(2159.0)) == 8294399.0
+    c = got["counters"]
+    npx = w * h
+    assert c["n_pixel_frames"] == npx * n and c["n_paths"] == npx * n
+    assert c["n_segments"] == c["n_hit_bounces"] + c["n_env_evals"]
+    assert c["n_hit_bounces"] == c["n_sphere_wins"] + c["n_tri_wins"]
+    assert c["n_sphere_tests"] == c["n_segments"] and c["n_box_tests"] == 2 * c["n_segments"]
+    assert c["n_env_evals"] <= c["n_paths"]
 
 
 # ---- ClosestHit on hand-made rays -----------------------------------------------------------------

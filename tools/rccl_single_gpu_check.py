@@ -1,5 +1,5 @@
 """RCCL on the image the renderer is bound to, with one rank (a one-GPU box cannot hold more): the
-kernels are launched on torch's stream through the C ABI, the all-reduce follows without a host
+kernels are launched on a torch stream through the C ABI, the all-reduce follows without a host
 synchronisation, and the result must be the plain render (a sum over one rank).  Prints OK or FAIL."""
 import os, socket, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,9 +19,12 @@ fd = R.make_frame_data(w, h, scene, R.BENCH_POSE, 1, 8)
 r = R.Renderer(w, h, device=0, variant=2); r.upload_scene(scene)
 sr = ShardedRenderer(r, dev)
 for step in range(3):
-    sr.accum.zero_()
-    r.render_frames(fd, 1, 16)
-    dist.all_reduce(sr.accum, op=dist.ReduceOp.SUM)     # RCCL on the tensor the kernels wrote, no host sync in between
+    sr.accum.fill_(5.0)                                     # junk, on torch's default stream
+    sr.stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(sr.stream):                      # the stream the library launches on
+        sr.accum.zero_()
+        r.render_frames(fd, 1, 16)
+        dist.all_reduce(sr.accum, op=dist.ReduceOp.SUM)     # RCCL on the tensor the kernels wrote, no host sync in between
     sr.resolve(16)
 torch.cuda.synchronize()
 got = sr.accum.cpu().numpy()
