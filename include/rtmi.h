@@ -175,6 +175,20 @@ RTMI_API int rtmi_render(rtmi_ctx *ctx, const rtmi_frame_data *fd);
 RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
                                 uint32_t first_frame, uint32_t n_frames);
 
+/* rtmi_render_frames for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid it.  No counterpart in the reference.  Same images, bit
+ * for bit, as rtmi_render_frames; it calls no hipMalloc / hipFree / hipEventCreate and records no
+ * timing events (rtmi_last_render_ms then has nothing to report).  The kernels' work list and counters
+ * live in a static device array inside the library (4 bytes per pixel + 256 bytes, held by every GPU
+ * the library runs on until the process ends) instead of buffers of the context, so the image may
+ * hold at most RTMI_NOALLOC_MAX_PIXELS pixels (RTMI_ERR_UNSUPPORTED beyond that, and with validation
+ * outputs enabled).  All contexts on one GPU share that array: no-allocation calls on the same GPU
+ * must not overlap (same stream, or otherwise ordered), or they race.  The kernel choice is that of
+ * rtmi_set_variant, except that primary segments are never kept between launches. */
+#define RTMI_NOALLOC_MAX_PIXELS 2097152u   /* 2^21: covers 1920 x 1080; 8 MiB of device memory per GPU */
+RTMI_API int rtmi_render_frames_noalloc(rtmi_ctx *ctx, const rtmi_frame_data *fd,
+                                        uint32_t first_frame, uint32_t n_frames);
+
 RTMI_API int rtmi_set_variant(rtmi_ctx *ctx, int variant);
 RTMI_API int rtmi_get_variant(const rtmi_ctx *ctx);
 /* Mode for the NEXT rtmi_upload_scene (default RTMI_ACCEL_AUTO); rtmi_get_acceleration tells what

@@ -15,6 +15,7 @@ COUNTER_NAMES = [
     "n_tri_wins", "n_hit_bounces", "n_env_evals", "n_pixel_frames", "n_paths", "n_segments",
 ]
 MISS_ID = 0xFFFFFFFF
+NOALLOC_MAX_PIXELS = 1 << 21
 
 VARIANT_MEGAKERNEL = 0
 VARIANT_REGENERATE = 1
@@ -103,6 +104,7 @@ PROTOTYPES = {
                                     C.POINTER(Mesh), C.c_uint32]),
     "rtmi_render": (C.c_int, [_ctx, C.POINTER(FrameData)]),
     "rtmi_render_frames": (C.c_int, [_ctx, C.POINTER(FrameData), C.c_uint32, C.c_uint32]),
+    "rtmi_render_frames_noalloc": (C.c_int, [_ctx, C.POINTER(FrameData), C.c_uint32, C.c_uint32]),
     "rtmi_set_variant": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_variant": (C.c_int, [_ctx]),
     "rtmi_set_acceleration": (C.c_int, [_ctx, C.c_int]),

@@ -51,6 +51,7 @@ struct rtmi_ctx {
     uint32_t *out_rgba8 = nullptr;
     uint32_t *hit_ids = nullptr, *chain_hash = nullptr, *rng_state = nullptr;
     uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list; hit_count[16] is variant 4's cursor
+    uint32_t *scratch = nullptr;   // this device's copy of the library's static work area (rtmi_render_frames_noalloc)
     int n_cus = 0;
     // Primary-segment cache (RTMI_VARIANT_AUTO only).  With an unchanged camera, scene and frame
     // constants every launch would classify the same pixels and find the same primary hits; they are
@@ -73,6 +74,15 @@ struct rtmi_ctx {
     bool bvh_active = false;           // the uploaded scene carries hierarchies and the kernels use them
     std::vector<rtmi_mesh> host_meshes;  // kept for range checks against frame data
 };
+
+// Work area of rtmi_render_frames_noalloc, which may not allocate: a launch-wide counter block (64
+// words: [0] length of the work list, [16] the pixel-streaming kernel's cursor) followed by the work
+// list of the classify + paths kernels, one word per pixel.  Every device the library runs on holds its
+// own copy at its own address (fetched once per context with hipGetSymbolAddress, never used by name in
+// host code); all no-allocation calls on one device share it.
+constexpr uint32_t kNoAllocMaxPixels = RTMI_NOALLOC_MAX_PIXELS;
+constexpr uint32_t kScratchHeadWords = 64u;
+static __device__ __align__(256) uint32_t scratch[kScratchHeadWords + kNoAllocMaxPixels];
 
 namespace {
 
@@ -160,6 +170,8 @@ int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out)
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
+    // this device's copy of the static work area (the symbol's name is not a device address in host code)
+    if ((e = hipGetSymbolAddress(reinterpret_cast<void **>(&c->scratch), HIP_SYMBOL(scratch))) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -487,9 +499,10 @@ static int ensure_validation_buffers(rtmi_ctx *c)
     return RTMI_OK;
 }
 
-int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames)
+// Both render entry points.  no_alloc: use the library's static work area instead of the context's
+// buffers, never store primary segments, record no events: nothing on this path allocates.
+static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames, bool no_alloc)
 {
-    constexpr bool no_alloc = false;
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     if (!fd) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: frame data is NULL");
     if (!c->has_scene) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_render: no scene uploaded");
@@ -502,6 +515,12 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     if ((uint32_t)fd->window[0] != c->width || (uint32_t)fd->window[1] != c->height)
         return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: window %gx%g does not match context %ux%u",
                     (double)fd->window[0], (double)fd->window[1], c->width, c->height);
+    if (no_alloc) {
+        if (n_pixels(c) > kNoAllocMaxPixels)
+            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render_frames_noalloc: %ux%u = %zu pixels exceed the static work area of %u pixels",
+                        c->width, c->height, n_pixels(c), kNoAllocMaxPixels);
+        if (c->validate) return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render_frames_noalloc: not available with validation outputs enabled");
+    }
     if (int rc = use_device(c)) return rc;
     if (c->validate)
         if (int rc = ensure_validation_buffers(c)) return rc;
@@ -534,8 +553,8 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.accum = c->accum;
     p.out_rgba8 = c->out_rgba8;
     p.hit_ids = c->hit_ids;
-    p.hit_list = c->hit_list;
-    p.hit_count = c->hit_count;
+    p.hit_list = no_alloc ? c->scratch + kScratchHeadWords : c->hit_list;
+    p.hit_count = no_alloc ? c->scratch : c->hit_count;
     p.stream_cursor = p.hit_count + 16;
     p.n_cus = (uint32_t)c->n_cus;
     p.chain_hash = c->chain_hash;
@@ -626,6 +645,18 @@ int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     }
     c->timed = events && !c->ev_logging;
     return RTMI_OK;
+}
+
+int rtmi_render_frames(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames)
+{
+    return render_impl(c, fd, first_frame, n_frames, false);
+}
+
+// No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+// graph capture, tight serving loops, harnesses that forbid it).
+int rtmi_render_frames_noalloc(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames)
+{
+    return render_impl(c, fd, first_frame, n_frames, true);
 }
 
 int rtmi_render(rtmi_ctx *c, const rtmi_frame_data *fd)

@@ -259,6 +259,10 @@ class Renderer:
     def render_frames(self, fd, first_frame, n_frames):
         self._check(self._lib.rtmi_render_frames(self._ctx, C.byref(fd), first_frame, n_frames))
 
+    def render_frames_noalloc(self, fd, first_frame, n_frames):
+        """rtmi_render_frames_noalloc: the same images from a call that allocates nothing."""
+        self._check(self._lib.rtmi_render_frames_noalloc(self._ctx, C.byref(fd), first_frame, n_frames))
+
     def synchronize(self):
         self._check(self._lib.rtmi_synchronize(self._ctx))
 

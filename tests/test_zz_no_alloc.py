@@ -1,0 +1,95 @@
+"""rtmi_render_frames_noalloc (the entry point that allocates nothing) against rtmi_render_frames,
+through the C ABI, bit for bit.  Collected last: its two calls share the library's static work area,
+the second with a smaller image, so stale contents of the first call's work list lie behind the
+second call's entries."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(rtmi, case, variant, accel=None, scene=None, fd=None):
+    """(image, display) of the plain entry point and of the no-allocation one, same inputs."""
+    sc = scene if scene is not None else cases.product_scene(case)
+    fd = fd if fd is not None else cases.product_frame_data(case, sc)
+    w, h = case["size"]
+    out = []
+    for noalloc in (False, True):
+        with rtmi.Renderer(w, h, variant=variant) as r:
+            if accel is not None:
+                r.set_acceleration(accel)
+            r.upload_scene(sc)
+            if case.get("seed_accum"):
+                r.write_accum(cases.seed_accum(case))
+            (r.render_frames_noalloc if noalloc else r.render_frames)(fd, case["first"], case["n"])
+            out.append((r.read_accum(), r.read_output_rgba8()))
+    return out
+
+
+@pytest.mark.parametrize("variant", [2, 3, 1])
+def test_two_calls_in_a_row_second_one_smaller(rtmi, variant):
+    big = dict(cases.CASES["c2_spheres_bench_pose"], size=(640, 360), n=16)
+    small = dict(cases.CASES["c3_mesh_bench_pose"], size=(37, 19), n=9)
+    for case in (big, small):
+        (want, want8), (got, got8) = _pair(rtmi, case, variant)
+        same = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert same, "%dx%d: accumulation image differs in %d pixels" % (case["size"] + (int((got != want).any(axis=-1).sum()),))
+        assert np.array_equal(got8, want8)
+    # the small case is also a golden fixture's scene: the plain entry point is itself pinned to the oracle
+    case = cases.CASES["c3_mesh_bench_pose"]
+    (want, want8), (got, got8) = _pair(rtmi, case, variant)
+    gold = cases.load_golden("c3_mesh_bench_pose")
+    assert cases.bits_equal(got, gold["accum"]) and np.array_equal(got8, gold["rgba8"])
+
+
+def test_hierarchy_scene_and_continued_sum(rtmi):
+    """The pixel-streaming kernel takes its cursor from the same static area; then a launch that continues a sum."""
+    big, pose = rtmi.scenes.stress_scene(600, (10, 10), 2, seed=3, extent=3.0)
+    for size, n in (((96, 54), 3), ((48, 27), 2)):
+        case = dict(size=size, first=1, n=n)
+        fd = rtmi.make_frame_data(size[0], size[1], big, pose=pose, rays_per_pixel=1, max_bounce=8)
+        for variant in (4, 2):
+            (want, want8), (got, got8) = _pair(rtmi, case, variant, accel=rtmi.abi.ACCEL_BVH, scene=big, fd=fd)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got8, want8)
+    case = cases.CASES["reference_defaults_rpp4_continue"]
+    (want, want8), (got, got8) = _pair(rtmi, case, 2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got8, want8)
+    assert cases.bits_equal(got, cases.load_golden("reference_defaults_rpp4_continue")["accum"])
+
+
+def test_limits_and_errors(rtmi):
+    a = rtmi.abi
+    case = cases.CASES["c3_mesh_bench_pose"]
+    sc = cases.product_scene(case)
+    # one pixel more than the static work area holds
+    w, h = 2048, 1025
+    assert w * h > a.NOALLOC_MAX_PIXELS
+    fd = rtmi.make_frame_data(w, h, sc, rtmi.BENCH_POSE, 1, 4)
+    with rtmi.Renderer(w, h) as r:
+        r.upload_scene(sc)
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.render_frames_noalloc(fd, 1, 1)
+        assert e.value.code == a.ERR_UNSUPPORTED and "exceed" in str(e.value)
+        r.render_frames(fd, 1, 1)            # the plain entry point still serves this size
+        r.synchronize()
+    # exactly the maximum is accepted
+    w, h = 2048, 1024
+    fd = rtmi.make_frame_data(w, h, sc, rtmi.BENCH_POSE, 1, 4)
+    with rtmi.Renderer(w, h, variant=2) as r:
+        r.upload_scene(sc)
+        r.render_frames_noalloc(fd, 1, 2)
+        got = r.read_accum()
+        r.render_frames(fd, 1, 2)
+        assert np.array_equal(got.view(np.uint32), r.read_accum().view(np.uint32))
+        r.enable_validation(True)
+        with pytest.raises(rtmi.RtmiError) as e:
+            r.render_frames_noalloc(fd, 1, 1)
+        assert e.value.code == a.ERR_UNSUPPORTED
+        r.enable_validation(False)
+        r.render_frames_noalloc(fd, 1, 1)
+        with pytest.raises(rtmi.RtmiError):
+            r.last_render_ms()               # the call records no timing events
