@@ -246,6 +246,11 @@ RTMI_API int rtmi_reset_counters(rtmi_ctx *ctx);
  * for n inputs.  op: 0 1/x, 1 sqrt, 2 log2 (library polynomial), 3 exp2 (library polynomial),
  * 4 uint32 -> float scaled by 2^-32 (input reinterpreted as uint32), 5 pow(x, y), 6 x / y. */
 RTMI_API int rtmi_selftest_math(rtmi_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
+/* GetEnvironmentLight (RT.comp:390-406) of n arbitrary directions (3 floats each) under fd's sky constants:
+ * rgb per direction.  wave_form = 0 evaluates the per-lane routine, 1 the routine the path kernels use,
+ * which shares the pow evaluations of a wave's directions out over its lanes. */
+RTMI_API int rtmi_selftest_env_light(rtmi_ctx *ctx, const rtmi_frame_data *fd, const float *directions, size_t n,
+                                     int wave_form, float *rgb_out);
 /* The kernels replace sqrt, 1/x and x / constant by shorter instruction sequences wherever the
  * argument is in the normal range.  This hook compares such a sequence with the general operation for
  * EVERY binary32 bit pattern the sequence is used for.  op: 0 sqrt, 1 reciprocal, 2 division by

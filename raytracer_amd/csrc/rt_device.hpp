@@ -256,7 +256,11 @@ struct Hit {
 };
 
 struct Counters {
+#ifdef RT_PATHS_PROFILE
+    uint32_t c[16];   // profiling build of k_paths: lane-occupancy tallies instead of event counters
+#else
     uint32_t c[11];
+#endif
 };
 
 // ClosestHit of Raytracing.comp:338-388 with the ray-invariant terms hoisted and everything that is
@@ -304,7 +308,16 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
         // (a discriminant below 2^-96 is outside the short square root's range: such a ray goes through the
         // literal evaluation below)
         auto candidate = [&](float b, float disc, uint32_t i) {
+#ifdef RT_PATHS_PROFILE
+            {
+                const unsigned long long m = __ballot(disc >= 0.0f && b < 0.0f);
+                if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) cn.c[12]++;  // block runs
+            }
+#endif
             if (disc >= 0.0f && b < 0.0f) {
+#ifdef RT_PATHS_PROFILE
+                cn.c[11]++;
+#endif
                 ambiguous = ambiguous || !sqrt_rn_admits(disc);
                 const float n = -b - sqrt_rn(disc);
                 if (n > thr_lo && n < best_n) {
@@ -336,6 +349,13 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
             best.mat = best_i;
             ambiguous = ambiguous || !(best.t < kFltMax);
         }
+#ifdef RT_PATHS_PROFILE
+        {
+            const unsigned long long m = __ballot(ambiguous);
+            if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) cn.c[14]++;
+            if (ambiguous) cn.c[13]++;
+        }
+#endif
         if (ambiguous) {
             // literal evaluation order of the shader, one divide per sphere
             best.t = kFltMax;
@@ -488,6 +508,122 @@ __device__ __forceinline__ V3 env_light(const Sky &sky, V3 d)
     V3 base = gmix(sky.ground, grad, g2s);
     float add = sun * mask;
     return mk(base.x + add, base.y + add, base.z + add);
+}
+
+// log2_poly for x in [2^-126, FLT_MAX] and exp2_poly for x in [-125, 127]: the same operations in the same
+// order as the general routines, without the scaling of denormals, the range reduction of huge or tiny
+// results and the final selections for special inputs, none of which these arguments can trigger.  The bits
+// returned are those of log2_poly / exp2_poly.
+__device__ __forceinline__ bool log2_poly_normal_admits(float x) { return x >= __uint_as_float(0x00800000u) && x <= kFltMax; }
+__device__ __forceinline__ float log2_poly_normal(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    const bool big = m > 1.41421356237f;
+    m = big ? m * 0.5f : m;
+    e += big ? 1 : 0;
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f + -1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f + -1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f + -1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f + -2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (p * f) * z;
+    y = y - 0.5f * z;
+    float r = y * 0.44269504088896340736f;
+    r = r + f * 0.44269504088896340736f;
+    r = r + y;
+    r = r + f;
+    r = r + (float)e;
+    return r;
+}
+__device__ __forceinline__ bool exp2_poly_normal_admits(float x) { return x >= -125.0f && x <= 127.0f; }
+__device__ __forceinline__ float exp2_poly_normal(float x)
+{
+    float fl = floorf(x);
+    int n = (int)fl;
+    float r = x - fl;
+    const bool up = r > 0.5f;
+    n += up ? 1 : 0;
+    r = up ? r - 1.0f : r;
+    float p = 1.535336188319500e-4f;
+    p = p * r + 1.339887440266574e-3f;
+    p = p * r + 9.618437357674640e-3f;
+    p = p * r + 5.550332471162809e-2f;
+    p = p * r + 2.402264791363012e-1f;
+    p = p * r + 6.931472028550421e-1f;
+    p = p * r + 1.0f;
+    return p * __uint_as_float((uint32_t)(n + 127) << 23);   // -125 <= n <= 127
+}
+
+// GetEnvironmentLight (Raytracing.comp:390-406) for a whole wave: every lane calls it, `want` lanes hold
+// a direction whose sky radiance is needed; the value returned to the other lanes is meaningless.
+//
+// Two thirds of the instructions of env_light are its two pow() evaluations, and a lane needs them only
+// for part of its directions: pow(smoothstep(0, 0.4, d.y), 0.35) is exactly 1 from d.y = 0.4 upwards and
+// exactly 0 from d.y = 0 downwards (the smoothstep is exactly 1 resp. +0 there, the polynomial log2 of 1 is
+// exactly 0 and exp2 of 0 exactly 1, and pow(0, y > 0) is 0 by definition), and the sun term is pow(0, focus)
+// = 0 for every direction that points away from the sun.  The pow evaluations that remain (both kinds
+// together are usually fewer than 64 per call) are handed out to the lanes of the wave, idle ones included,
+// through an LDS mailbox `mail` of kSkyMail floats owned by the wave (56, not 64: with the frame ring of the
+// path kernel that is exactly 5 of the 1280-byte units in which a CU hands out its LDS; one float more
+// would cost a sixth unit and with it three of the 24 waves a CU holds), evaluated by ONE instance of the
+// pow code, and read back with cross-lane reads.  Each evaluation is the arithmetic env_light performs, so the bits are
+// the same.  Likewise smoothstep(-0.01, 0, d.y) is exactly 1 for d.y >= 0 and exactly +0 for d.y <= -0.01
+// and is only evaluated when some lane's direction lies in between.
+constexpr uint32_t kSkyMail = 56u;
+__device__ __forceinline__ V3 env_light_wave(const Sky &sky, V3 d, bool want, uint32_t lane, float *mail)
+{
+    const float grad_s = smoothstep_const(0.0f, 0.4f, d.y);
+    const float sun_x = gmax(0.0f, dot(d, sky.neg_sun));
+    const bool need_a = want && !(grad_s == 0.0f || grad_s == 1.0f || grad_s != grad_s);   // pow(s, 0.35) = s for 0, 1, NaN
+    const bool need_b = want && !(sun_x == 0.0f && sky.sun_focus > 0.0f);                     // pow(0, y > 0) = 0
+    float pow_a = grad_s, pow_b = 0.0f;
+    const unsigned long long mask_a = __ballot(need_a), mask_b = __ballot(need_b);
+    const uint32_t n_a = (uint32_t)__popcll(mask_a), total = n_a + (uint32_t)__popcll(mask_b);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t rank_a = (uint32_t)__popcll(mask_a & below), rank_b = n_a + (uint32_t)__popcll(mask_b & below);
+    for (uint32_t base = 0u; base < total; base += kSkyMail) {   // wave-uniform; a second trip only beyond kSkyMail requests
+        const uint32_t slot_a = rank_a - base, slot_b = rank_b - base;   // a request is served in this trip if its slot is < kSkyMail
+        const bool now_a = need_a && slot_a < kSkyMail, now_b = need_b && slot_b < kSkyMail;
+        if (now_a) mail[slot_a] = grad_s;
+        if (now_b) mail[slot_b] = sun_x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // lane w evaluates request base + w (lanes beyond the last request evaluate whatever the mailbox holds)
+        const bool serving = lane < kSkyMail && base + lane < total;
+        const float x = mail[lane < kSkyMail ? lane : 0u];
+        const float y = (base + lane < n_a) ? 0.35f : sky.sun_focus;
+        float lg;
+        if (__ballot(serving && !log2_poly_normal_admits(x)) == 0ull) lg = log2_poly_normal(x);
+        else lg = log2_poly(x);
+        const float arg = y * lg;
+        float r;
+        if (__ballot(serving && !exp2_poly_normal_admits(arg)) == 0ull) r = exp2_poly_normal(arg);
+        else r = exp2_poly(arg);
+        r = (x == 0.0f && y > 0.0f) ? 0.0f : r;
+        const float back_a = __shfl(r, (int)(slot_a & 63u), 64), back_b = __shfl(r, (int)(slot_b & 63u), 64);
+        pow_a = now_a ? back_a : pow_a;
+        pow_b = now_b ? back_b : pow_b;
+        __builtin_amdgcn_wave_barrier();   // the mailbox is rewritten by the next trip
+    }
+    const V3 grad = gmix(sky.horizon, sky.zenith, pow_a);
+    const float sun = pow_b * sky.sun_intensity;
+    // smoothstep(-0.01, 0, d.y): exactly 1 for d.y >= 0, exactly +0 for d.y <= -0.01
+    const bool above = d.y >= 0.0f, between = !above && !(d.y <= -0.01f);   // NaN counts as between
+    float g2s = above ? 1.0f : 0.0f;
+    if (__ballot(want && between) != 0ull) g2s = smoothstep_const(-0.01f, 0.0f, d.y);
+    const float mask = (g2s >= 1.0f) ? 1.0f : 0.0f;
+    const V3 base_c = gmix(sky.ground, grad, g2s);
+    const float add = sun * mask;
+    return mk(base_c.x + add, base_c.y + add, base_c.z + add);
 }
 
 // The hit branch of Trace, Raytracing.comp:417-431.

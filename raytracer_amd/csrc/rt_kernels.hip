@@ -113,7 +113,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 __device__ __forceinline__ void zero(Counters &c)
 {
 #pragma unroll
-    for (int i = 0; i < 11; i++) c.c[i] = 0u;
+    for (int i = 0; i < (int)(sizeof(c.c) / sizeof(c.c[0])); i++) c.c[i] = 0u;
 }
 
 // Closest hit by the uniform loops or through the hierarchy; the choice is made per launch.
@@ -798,6 +798,31 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest_exhaustive(int op, f
     }
 }
 
+// GetEnvironmentLight of n arbitrary directions (test hook): the per-lane routine, or the routine that
+// shares the pow evaluations out over the wave (one wave per workgroup, as in k_paths; every third lane
+// holds no direction, as lanes without an escaping path do there)
+__global__ __launch_bounds__(64) void k_selftest_env(const RenderParams p, const float *__restrict__ dirs, size_t n, int wave_form,
+                                                     float *__restrict__ rgb_out)
+{
+    __shared__ float mail[kSkyMail];
+    const Sky sky = make_sky(p);
+    const uint32_t lane = threadIdx.x;
+    // 42 directions per workgroup in the wave form (lanes 2, 5, 8, ... idle), 64 otherwise
+    const bool idle = wave_form && lane % 3u == 2u;
+    const size_t per_group = wave_form ? 43u : 64u;
+    const size_t i = (size_t)blockIdx.x * per_group + (wave_form ? lane - lane / 3u : lane);
+    const bool want = !idle && i < n;
+    const V3 d = want ? mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]) : mk(0.3f, -0.005f, __uint_as_float(0x7FC00000u));
+    V3 e;
+    if (wave_form) e = env_light_wave(sky, d, want, lane, mail);
+    else e = env_light(sky, d);
+    if (want) {
+        rgb_out[3 * i + 0] = e.x;
+        rgb_out[3 * i + 1] = e.y;
+        rgb_out[3 * i + 2] = e.z;
+    }
+}
+
 // closest hit of n arbitrary rays against the uploaded scene (test hook)
 template <bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, uint32_t n_spheres, uint32_t n_meshes,
@@ -826,6 +851,14 @@ hipError_t rt_launch_selftest_hit(const DeviceScene &sc, bool use_bvh, uint32_t 
     else
         hipLaunchKernelGGL(k_selftest_hit<false>, grid, dim3(kBlockThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins,
                            dirs, n, t_out, prim_out);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_selftest_env(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out, hipStream_t stream)
+{
+    const size_t per_group = wave_form ? 43u : 64u;
+    const dim3 grid((unsigned)((n + per_group - 1) / per_group), 1, 1);
+    hipLaunchKernelGGL(k_selftest_env, grid, dim3(64, 1, 1), 0, stream, p, dirs, n, wave_form, rgb_out);
     return hipGetLastError();
 }
 

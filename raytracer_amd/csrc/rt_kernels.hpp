@@ -53,5 +53,6 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
 hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
 hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream);
+hipError_t rt_launch_selftest_env(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out, hipStream_t stream);
 hipError_t rt_launch_selftest_exhaustive(int op, float c, unsigned long long *out, hipStream_t stream);
 hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);

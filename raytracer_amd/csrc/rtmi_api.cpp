@@ -499,6 +499,27 @@ static int ensure_validation_buffers(rtmi_ctx *c)
     return RTMI_OK;
 }
 
+// the uniform block's camera, image and sky members (Raytracing.comp:3-24) as kernel arguments
+static void fill_frame_params(const rtmi_ctx *c, const rtmi_frame_data *fd, RenderParams &p)
+{
+    memset(&p, 0, sizeof p);
+    memcpy(p.inv_proj, fd->camera_inverse_projection, sizeof p.inv_proj);
+    memcpy(p.inv_view, fd->camera_inverse_view, sizeof p.inv_view);
+    memcpy(p.cam_pos, fd->camera_pos, sizeof p.cam_pos);
+    p.window_w = fd->window[0];
+    p.window_h = fd->window[1];
+    p.width = c->width;
+    p.height = c->height;
+    p.rays_per_pixel = fd->rays_per_pixel;
+    p.max_bounce = fd->max_bounce_limit;
+    memcpy(p.sky_horizon, fd->sky_color_horizon, sizeof p.sky_horizon);
+    memcpy(p.sky_zenith, fd->sky_color_zenith, sizeof p.sky_zenith);
+    memcpy(p.sun_dir, fd->sun_light_direction, sizeof p.sun_dir);
+    memcpy(p.ground, fd->ground_color, sizeof p.ground);
+    p.sun_focus = fd->sun_focus;
+    p.sun_intensity = fd->sun_intensity;
+}
+
 // Both render entry points.  no_alloc: use the library's static work area instead of the context's
 // buffers, never store primary segments, record no events: nothing on this path allocates.
 static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_frame, uint32_t n_frames, bool no_alloc)
@@ -526,22 +547,7 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         if (int rc = ensure_validation_buffers(c)) return rc;
 
     RenderParams p;
-    memset(&p, 0, sizeof p);
-    memcpy(p.inv_proj, fd->camera_inverse_projection, sizeof p.inv_proj);
-    memcpy(p.inv_view, fd->camera_inverse_view, sizeof p.inv_view);
-    memcpy(p.cam_pos, fd->camera_pos, sizeof p.cam_pos);
-    p.window_w = fd->window[0];
-    p.window_h = fd->window[1];
-    p.width = c->width;
-    p.height = c->height;
-    p.rays_per_pixel = fd->rays_per_pixel;
-    p.max_bounce = fd->max_bounce_limit;
-    memcpy(p.sky_horizon, fd->sky_color_horizon, sizeof p.sky_horizon);
-    memcpy(p.sky_zenith, fd->sky_color_zenith, sizeof p.sky_zenith);
-    memcpy(p.sun_dir, fd->sun_light_direction, sizeof p.sun_dir);
-    memcpy(p.ground, fd->ground_color, sizeof p.ground);
-    p.sun_focus = fd->sun_focus;
-    p.sun_intensity = fd->sun_intensity;
+    fill_frame_params(c, fd, p);
     p.sphere_number = fd->sphere_number;
     p.mesh_number = fd->mesh_number;
     p.first_frame = first_frame;
@@ -917,6 +923,29 @@ int rtmi_selftest_math(rtmi_ctx *c, int op, const float *x, const float *y, floa
     (void)hipFree(dx);
     (void)hipFree(dy);
     (void)hipFree(dout);
+    return rc;
+}
+
+int rtmi_selftest_env_light(rtmi_ctx *c, const rtmi_frame_data *fd, const float *directions, size_t n, int wave_form, float *rgb_out)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!fd || !directions || !rgb_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_selftest_env_light: NULL argument");
+    if (n == 0) return RTMI_OK;
+    if (int rc = use_device(c)) return rc;
+    RenderParams p;
+    fill_frame_params(c, fd, p);
+    float *dbuf = nullptr;
+    hipError_t e = hipMalloc(&dbuf, n * 6 * sizeof(float));
+    if (e != hipSuccess || !dbuf)
+        return fail(c, e == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP, "rtmi_selftest_env_light: hipMalloc: %s",
+                    hipGetErrorString(e));
+    int rc = RTMI_OK;
+    e = hipMemcpyAsync(dbuf, directions, n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rt_launch_selftest_env(p, dbuf, n, wave_form != 0, dbuf + 3 * n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, dbuf + 3 * n, n * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_env_light: %s", hipGetErrorString(e));
+    (void)hipFree(dbuf);
     return rc;
 }
 

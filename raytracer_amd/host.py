@@ -348,6 +348,14 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
+    def selftest_env_light(self, fd, directions, wave_form):
+        """Sky radiance [n, 3] of directions [n, 3] under fd's sky constants; wave_form picks the routine."""
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        out = np.empty_like(d)
+        self._check(self._lib.rtmi_selftest_env_light(self._ctx, C.byref(fd), d.ctypes.data, len(d), 1 if wave_form else 0,
+                                                      out.ctypes.data))
+        return out
+
     def selftest_exhaustive(self, op, divisor=1.0):
         """(patterns tested, mismatches, smallest mismatching bit pattern) of a short exact routine
         against the general operation: op 0 sqrt, 1 reciprocal, 2 division by `divisor`."""

@@ -253,6 +253,38 @@ def test_env_light_regions(oracle):
     assert np.allclose(list(rgb), [0.2 + 0.4, 0.56 + 0.4, 0.95 + 0.4], atol=1e-5)
 
 
+def test_env_light_terms_that_are_constant_by_region(oracle):
+    """What the GPU's wave-shared sky routine relies on: below d.y = 0 the gradient term is exactly
+    pow(0, 0.35) = 0 and from d.y = 0.4 on exactly pow(1, 0.35) = 1; the ground / sky blend is exactly 0 up to
+    d.y = -0.01 and exactly 1 from d.y = 0 on; the sun term is exactly 0 for directions facing away from the
+    sun.  Checked on the oracle by comparing with closed forms built from those constants."""
+    L = oracle.lib()
+    fd = oracle.frame_data(64, 64)
+    f = np.float32
+    hor, zen, gnd = (np.array(list(v)[:3], dtype=f) for v in (fd.sky_horizon, fd.sky_zenith, fd.ground))
+    rgb = (C.c_float * 3)()
+
+    def env(d):
+        L.orc_env_light(C.byref(fd), oracle.fl3(*[float(v) for v in d]), rgb)
+        return np.array(rgb[:], dtype=f)
+
+    assert list(fd.sun_dir)[:3] == [f(-0.4)] * 3
+    away = lambda y: np.array([-4.0, y, -4.0], dtype=f)    # dot with -(sun.xzy) = 0.4 (y - 8) < 0 for y < 8
+    one, zero = f(1.0), f(0.0)
+    for y in (f(0.4), np.nextafter(f(0.4), f(1)), f(0.7), f(5.0)):
+        grad = hor * (one - one) + zen * one
+        assert np.array_equal(env(away(y)), (gnd * (one - one) + grad * one) + zero * one)
+    for y in (f(0.0), f(-0.0)):
+        grad = hor * (one - zero) + zen * zero
+        assert np.array_equal(env(away(y)), (gnd * (one - one) + grad * one) + zero * one)
+    for y in (f(-0.01), np.nextafter(f(-0.01), f(-1)), f(-0.3), f(-np.inf)):
+        grad = hor * (one - zero) + zen * zero
+        assert np.array_equal(env(away(y)), (gnd * (one - zero) + grad * zero) + zero * zero)
+    # strictly between the regions the terms do vary
+    assert not np.array_equal(env(away(f(0.2))), env(away(f(0.3))))
+    assert not np.array_equal(env(away(f(-0.002))), env(away(f(-0.008))))
+
+
 def test_default_pose_sees_no_geometry(oracle):
     sc = oracle.reference_scene()
     fd = oracle.frame_data(160, 90, rpp=1, max_bounce=4, scene=sc)
