@@ -917,11 +917,14 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
         // k_paths for this scene: with a hierarchy, without meshes (no mesh code at all), or with meshes
         // (triangle tests shared by the lanes of a wave)
         const bool meshes = p.mesh_number != 0u;
+        const bool rpp1 = p.rays_per_pixel == 1u;
         auto launch_paths = [&](auto validate_c, auto cached_c) {
             constexpr bool V = decltype(validate_c)::value, C = decltype(cached_c)::value;
             if (bvh) hipLaunchKernelGGL((k_paths<V, true, C, true>), grid_paths, block_paths, 0, stream, p);
-            else if (meshes) hipLaunchKernelGGL((k_paths<V, false, C, true>), grid_paths, block_paths, 0, stream, p);
-            else hipLaunchKernelGGL((k_paths<V, false, C, false>), grid_paths, block_paths, 0, stream, p);
+            else if (meshes && rpp1) hipLaunchKernelGGL((k_paths<V, false, C, true, true>), grid_paths, block_paths, 0, stream, p);
+            else if (meshes) hipLaunchKernelGGL((k_paths<V, false, C, true, false>), grid_paths, block_paths, 0, stream, p);
+            else if (rpp1) hipLaunchKernelGGL((k_paths<V, false, C, false, true>), grid_paths, block_paths, 0, stream, p);
+            else hipLaunchKernelGGL((k_paths<V, false, C, false, false>), grid_paths, block_paths, 0, stream, p);
         };
         if (cache == RT_CACHE_LOAD) {
             hipLaunchKernelGGL(k_sky_add, dim3((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1), block, 0, stream, p);
