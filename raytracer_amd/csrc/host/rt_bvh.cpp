@@ -87,7 +87,7 @@ struct Builder {
             r.box.Grow(p.lo, p.hi);
             if (p.margin_floor < r.margin_floor) r.margin_floor = p.margin_floor;
         }
-        r.ref = kLeafFlag | ((e - b) << 28) | (leaf_base + b);
+        r.ref = kLeafFlag | ((e - b) << 28) | (leaf_base + b);   // leaf_base + b < 2^27 (callers check)
         return r;
     }
 
@@ -304,6 +304,73 @@ uint32_t BuildBvh(const std::vector<PrimBox> &boxes, std::vector<BvhNode> &nodes
     const uint32_t root = bld.Range(0, n, kMaxDepth, nodes, kForkLevels).ref;
     for (uint32_t k = 0; k < n; k++) order[k] = bld.items[k].id;
     return root;
+}
+
+void QuantizeNodes(const std::vector<BvhNode> &nodes, QFrame &frame, std::vector<QNode> &out)
+{
+    // the frame: the finite planes' range per axis
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    auto take = [&](const float *l, const float *h) {
+        // an inverted box (a child without any primitive that has coordinates) is not part of the scene
+        if (!(l[0] <= h[0]) || !(l[1] <= h[1]) || !(l[2] <= h[2])) return;
+        for (int a = 0; a < 3; a++) {
+            if (std::isfinite(l[a]) && l[a] < lo[a]) lo[a] = l[a];
+            if (std::isfinite(h[a]) && h[a] > hi[a]) hi[a] = h[a];
+            // a box that is infinite on one side still has a finite plane on the other
+            if (std::isfinite(h[a]) && h[a] < lo[a]) lo[a] = h[a];
+            if (std::isfinite(l[a]) && l[a] > hi[a]) hi[a] = l[a];
+        }
+    };
+    for (const BvhNode &nd : nodes) {
+        take(nd.l_lo, nd.l_hi);
+        take(nd.r_lo, nd.r_hi);
+    }
+    frame = QFrame();
+    for (int a = 0; a < 3; a++) {
+        if (!(lo[a] <= hi[a])) {
+            lo[a] = 0.0;
+            hi[a] = 0.0;
+        }
+        frame.origin[a] = (float)lo[a];
+        if ((double)frame.origin[a] > lo[a]) frame.origin[a] = std::nextafterf(frame.origin[a], -INFINITY);
+        const double ext = hi[a] - (double)frame.origin[a];
+        float st = (float)(ext / 65534.0);   // one step of slack at the top for the rounding below
+        if ((double)st * 65534.0 < ext) st = std::nextafterf(st, INFINITY);
+        if (!(st > 0.0f) || !std::isfinite(st)) st = 1.0f;
+        frame.step[a] = st;
+        frame.extent_max = std::max(frame.extent_max, 65535.0f * st);
+        frame.origin_max = std::max(frame.origin_max, std::fabs(frame.origin[a]));
+    }
+    // one child box -> three packed axes; returns false if a bound cannot be represented (infinite)
+    auto pack = [&](const float *l, const float *h, uint32_t *q) {
+        bool bounded = true;
+        const bool empty = !(l[0] <= h[0]) || !(l[1] <= h[1]) || !(l[2] <= h[2]);   // inverted (or NaN, which Grow never stores)
+        for (int a = 0; a < 3; a++) {
+            if (empty) {
+                q[a] = 0x0000FFFFu;   // lower 0xFFFF, upper 0: no ray enters
+                continue;
+            }
+            const double o = frame.origin[a], st = frame.step[a];
+            long long ql = (long long)std::floor(((double)l[a] - o) / st) - 1;   // one step of slack each way: the
+            long long qh = (long long)std::ceil(((double)h[a] - o) / st) + 1;    // divisions above are rounded
+            if (!std::isfinite(l[a]) || !std::isfinite(h[a]) || ql < -1 || qh > 65536) bounded = false;
+            ql = std::min(std::max(ql, 0ll), 65535ll);
+            qh = std::min(std::max(qh, 0ll), 65535ll);
+            // what was clamped must still enclose
+            if (o + (double)ql * st > (double)l[a] || o + (double)qh * st < (double)h[a]) bounded = false;
+            q[a] = (uint32_t)ql | ((uint32_t)qh << 16);
+        }
+        return bounded || empty;
+    };
+    out.resize(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const BvhNode &nd = nodes[k];
+        QNode &q = out[k];
+        q.left = nd.left;
+        q.right = nd.right;
+        if (!pack(nd.l_lo, nd.l_hi, q.l)) q.left |= kUnboundedFlag;
+        if (!pack(nd.r_lo, nd.r_hi, q.r)) q.right |= kUnboundedFlag;
+    }
 }
 
 }  // namespace rtmi

@@ -137,7 +137,7 @@ int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nod
                    uint32_t *order_out, uint32_t *root_out)
 {
     if ((n && !boxes) || (n && !order_out) || !root_out) return RTMI_ERR_INVALID_ARGUMENT;
-    if (n > rtmi::kMaxPrimitives || (uint64_t)leaf_base + n >= (1u << 28)) return RTMI_ERR_UNSUPPORTED;
+    if (n > rtmi::kMaxPrimitives || (uint64_t)leaf_base + n >= (1u << 27)) return RTMI_ERR_UNSUPPORTED;
     try {
         std::vector<rtmi::PrimBox> pb(n);
         for (uint32_t i = 0; i < n; i++)

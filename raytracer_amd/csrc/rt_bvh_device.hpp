@@ -158,30 +158,52 @@ __device__ __forceinline__ bool bvh_at_inner(const BvhWalk &w)
 // the ray can reach (the other one, if reachable too, goes on the stack).  stack points at this lane's
 // first slot; consecutive levels are stride words apart.
 //
+// A node is 32 bytes: two child references and twelve 16-bit plane positions q in the scene's frame,
+// plane = origin + q * step.  The float 2^23 + q is assembled in place (its bits are 0x4B000000 | q) and
+// one fused multiply-add per plane gives the plane relative to the ray origin:
+//     (2^23 + q) * step + (origin - 2^23 * step - o).
+// The upload chose q so that the quantised box encloses the child's box in exact arithmetic; what the
+// three roundings here (of origin - 2^23 step, of the subtraction of o, of the fused result) can move a
+// plane by is below 2^-24 (|origin| + 260 * 65535 step + 2 |plane - o|), which sc.bvh_slack and 2^-22 of
+// the largest distance component cover.
+//
 // Both boxes are grown by ONE margin, computed for their union: D^2 over the union bounds |oc|^2 for
-// everything below either child, and the smaller of the two radius floors gives the larger margin.
+// everything below either child, and the smallest radius in the hierarchy gives the largest margin.
 // The margin arithmetic is not part of the shader's arithmetic (it only has to be an upper bound), so
-// it uses fused multiply-adds.
+// it uses fused multiply-adds.  A child flagged unbounded (an infinite box) is visited whatever the ray.
+constexpr uint32_t kBvhUnbounded = 0x08000000u;
+constexpr uint32_t kBvhIndexMask = 0x07FFFFFFu;
+
 template <bool COUNT>
 __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uint32_t n_meshes, V3 o, Counters &cn, uint32_t *stack,
                                           uint32_t stride)
 {
-    const float4 *__restrict__ rec = sc.bvh_nodes + 4 * (size_t)w.ref;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    const uint4 *__restrict__ rec = sc.bvh_nodes + 2 * (size_t)(w.ref & kBvhIndexMask);
+    const uint4 n0 = rec[0], n1 = rec[1];
     if (COUNT) cn.c[3] += 2u;
     const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
+    const float floor_r = w.is(BvhWalk::kInSpheres) ? sc.bvh_sphere_floor : 0.0f;
     const float t_limit = w.best.t * kBvhTSlack;
-    const float l0x = q0.x - o.x, l1x = q1.x - o.x, r0x = q2.x - o.x, r1x = q3.x - o.x;
-    const float l0y = q0.y - o.y, l1y = q1.y - o.y, r0y = q2.y - o.y, r1y = q3.y - o.y;
-    const float l0z = q0.z - o.z, l1z = q1.z - o.z, r0z = q2.z - o.z, r1z = q3.z - o.z;
+    const float cx = sc.bvh_base[0] - o.x, cy = sc.bvh_base[1] - o.y, cz = sc.bvh_base[2] - o.z;
+    const float sx = sc.bvh_step[0], sy = sc.bvh_step[1], sz = sc.bvh_step[2];
+    // 2^23 + lower count, 2^23 + upper count
+    auto lower = [](uint32_t packed) { return __uint_as_float((packed & 0xFFFFu) | 0x4B000000u); };
+    auto upper = [](uint32_t packed) { return __uint_as_float(__builtin_amdgcn_alignbit(0x4B00u, packed, 16u)); };
+    const float l0x = __builtin_fmaf(lower(n0.z), sx, cx), l1x = __builtin_fmaf(upper(n0.z), sx, cx);
+    const float l0y = __builtin_fmaf(lower(n0.w), sy, cy), l1y = __builtin_fmaf(upper(n0.w), sy, cy);
+    const float l0z = __builtin_fmaf(lower(n1.x), sz, cz), l1z = __builtin_fmaf(upper(n1.x), sz, cz);
+    const float r0x = __builtin_fmaf(lower(n1.y), sx, cx), r1x = __builtin_fmaf(upper(n1.y), sx, cx);
+    const float r0y = __builtin_fmaf(lower(n1.z), sy, cy), r1y = __builtin_fmaf(upper(n1.z), sy, cy);
+    const float r0z = __builtin_fmaf(lower(n1.w), sz, cz), r1z = __builtin_fmaf(upper(n1.w), sz, cz);
     const float mx = fmaxf(fmaxf(fmaxf(fabsf(l0x), fabsf(l1x)), fabsf(r0x)), fabsf(r1x));
     const float my = fmaxf(fmaxf(fmaxf(fabsf(l0y), fabsf(l1y)), fabsf(r0y)), fabsf(r1y));
     const float mz = fmaxf(fmaxf(fmaxf(fabsf(l0z), fabsf(l1z)), fabsf(r0z)), fabsf(r1z));
     const float d2 = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
-    const float floor_r = fminf(q2.w, q3.w);
     // the hardware square root is good to 1 ulp; the factor 1 + 2^-20 keeps the result an upper bound
     const float grown = __builtin_amdgcn_sqrtf(__builtin_fmaf(kappa, d2, floor_r * floor_r)) * 1.00000095367431640625f;
-    const float e = __builtin_fmaf(1.9073486328125e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r);
+    // 2^-19 of the largest distance component for the slab arithmetic, 2^-22 of it and the frame's slack for
+    // the planes themselves
+    const float e = __builtin_fmaf(2.1457672119140625e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r) + sc.bvh_slack;
     // Entry and exit distances of the grown boxes.  NaN (0 * inf, inf - inf) makes a comparison false,
     // which keeps the box.
     const V3 inv = w.inv;
@@ -195,9 +217,9 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
     const float tl_far = fminf(fminf(fmaxf(a1, a2), fmaxf(a3, a4)), fmaxf(a5, a6));
     const float tr = fmaxf(fmaxf(fminf(b1, b2), fminf(b3, b4)), fminf(b5, b6));
     const float tr_far = fminf(fminf(fmaxf(b1, b2), fmaxf(b3, b4)), fmaxf(b5, b6));
-    const bool hl = !(tl_far < 0.0f) && !(tl > tl_far) && !(tl > t_limit);
-    const bool hr = !(tr_far < 0.0f) && !(tr > tr_far) && !(tr > t_limit);
-    const uint32_t L = __float_as_uint(q0.w), R = __float_as_uint(q1.w);
+    const uint32_t L = n0.x, R = n0.y;
+    const bool hl = ((L & kBvhUnbounded) != 0u) || (!(tl_far < 0.0f) && !(tl > tl_far) && !(tl > t_limit));
+    const bool hr = ((R & kBvhUnbounded) != 0u) || (!(tr_far < 0.0f) && !(tr > tr_far) && !(tr > t_limit));
     if (hl && hr) {
         const bool right_first = tr < tl;
         stack[(uint32_t)w.sp * stride] = right_first ? L : R;  // sp < kBvhStack: one entry per level
@@ -279,7 +301,7 @@ __device__ __forceinline__ void bvh_other(BvhWalk &w, const DeviceScene &sc, uin
 
     if (w.leaf_left == 0u) {
         // bvh_at_inner() is false, so ref names a leaf
-        w.leaf_pos = w.ref & 0x0FFFFFFFu;
+        w.leaf_pos = w.ref & kBvhIndexMask;
         w.leaf_left = (w.ref >> 28) & 7u;
     }
     const size_t e = w.leaf_pos;

@@ -226,7 +226,12 @@ struct DeviceScene {
     const float4 *materials;    // [S + M][2] {r, g, b, light} {smoothness, 0, 0, 0}
     uint32_t n_spheres, n_triangles, n_meshes;
     // bounding volume hierarchy (only for scenes too large for the uniform loops; null otherwise)
-    const float4 *bvh_nodes;        // [N][4]   {l.lo, bits(left)} {l.hi, bits(right)} {r.lo,-} {r.hi,-}
+    const uint4 *bvh_nodes;         // [N][2]   {left, right, l.x, l.y} {l.z, r.x, r.y, r.z}: child references and, per axis,
+                                    //          lower | upper << 16 step counts of the child boxes in the frame below
+    float bvh_base[3];              // frame origin - 2^23 * step per axis (the traversal builds 2^23 + q in place)
+    float bvh_step[3];
+    float bvh_slack;                // bound on the rounding of a dequantised plane relative to the ray origin
+    float bvh_sphere_floor;         // smallest radius in the sphere hierarchy (shrinks the margin of its boxes)
     const float4 *bvh_sphere_geom;  // [S]      sphere_geom in leaf order
     const uint32_t *bvh_sphere_id;  // [S]      sphere index of each leaf-order entry
     const float4 *bvh_tri_isect;    // [L][4]   tri_isect in leaf order (L = sum of the meshes' counts)

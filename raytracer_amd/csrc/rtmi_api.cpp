@@ -250,6 +250,9 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     const bool want_bvh = c->accel_mode == RTMI_ACCEL_BVH ||
                           (c->accel_mode == RTMI_ACCEL_AUTO && (uint64_t)nS + nT > kAutoBvhThreshold);
     std::vector<rtmi::BvhNode> nodes;
+    std::vector<rtmi::QNode> qnodes;   // what is uploaded: the nodes in their 32-byte form
+    rtmi::QFrame qframe;
+    float sphere_floor = 0.0f;
     std::vector<uint32_t> sphere_order, tri_order;  // leaf position -> primitive index
     std::vector<uint32_t> mesh_root(nM, rtmi::kEmptyRef);
     uint32_t sphere_root = rtmi::kEmptyRef;
@@ -257,7 +260,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     if (want_bvh) {
         uint64_t leaf_total = 0;
         for (uint32_t m = 0; m < nM; m++) leaf_total += (uint32_t)meshes[m].num_triangles;
-        if (nS > rtmi::kMaxPrimitives || leaf_total > rtmi::kMaxPrimitives)
+        if (nS > rtmi::kMaxPrimitives || leaf_total > rtmi::kMaxPrimitives || nS >= rtmi::kUnboundedFlag || leaf_total >= rtmi::kUnboundedFlag)
             return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than %llu primitives in a hierarchy",
                         (unsigned long long)rtmi::kMaxPrimitives);
         try {
@@ -270,6 +273,9 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
                     boxes[i].hi[a] = round_up((double)spheres[i].center[a] + r);
                 }
                 boxes[i].margin_floor = (float)(std::fabs((double)spheres[i].radius) * 0.999999);
+                // the smallest radius of all (not a number counts as 0): one margin floor for the whole hierarchy
+                const float f = boxes[i].margin_floor >= 0.0f ? boxes[i].margin_floor : 0.0f;
+                sphere_floor = (i == 0u || f < sphere_floor) ? f : sphere_floor;
             }
             // the sphere hierarchy on a thread of its own while the meshes are built below; its nodes
             // are the first in the node array either way
@@ -362,6 +368,10 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
                 std::vector<rtmi::BvhNode>().swap(mesh_nodes[m]);
                 std::vector<uint32_t>().swap(mesh_order[m]);
             }
+            if (nodes.size() >= rtmi::kUnboundedFlag)
+                return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: %zu hierarchy nodes exceed the reference format", nodes.size());
+            rtmi::QuantizeNodes(nodes, qframe, qnodes);
+            std::vector<rtmi::BvhNode>().swap(nodes);
         } catch (const std::bad_alloc &) {
             return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation failed while building hierarchies");
         } catch (const std::exception &ex) {
@@ -371,7 +381,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
             return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: building hierarchies failed");
         }
         off_nodes = align_up(total, 256);
-        off_bsph = align_up(off_nodes + nodes.size() * sizeof(rtmi::BvhNode), 256);
+        off_bsph = align_up(off_nodes + qnodes.size() * sizeof(rtmi::QNode), 256);
         off_bsid = align_up(off_bsph + (size_t)nS * 16, 256);
         off_btri = align_up(off_bsid + (size_t)nS * 4, 256);
         off_btid = align_up(off_btri + tri_order.size() * 64, 256);
@@ -440,7 +450,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     }
 
     if (want_bvh) {
-        if (!nodes.empty()) memcpy(blob.data() + off_nodes, nodes.data(), nodes.size() * sizeof(rtmi::BvhNode));
+        if (!qnodes.empty()) memcpy(blob.data() + off_nodes, qnodes.data(), qnodes.size() * sizeof(rtmi::QNode));
         float *bs = reinterpret_cast<float *>(blob.data() + off_bsph);
         uint32_t *bi = reinterpret_cast<uint32_t *>(blob.data() + off_bsid);
         for (uint32_t k = 0; k < nS; k++) {
@@ -471,7 +481,15 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->dscene.tri_shade = reinterpret_cast<const float4 *>(base + off_shd);
     c->dscene.mesh_box = reinterpret_cast<const float4 *>(base + off_box);
     c->dscene.materials = reinterpret_cast<const float4 *>(base + off_mat);
-    c->dscene.bvh_nodes = want_bvh ? reinterpret_cast<const float4 *>(base + off_nodes) : nullptr;
+    c->dscene.bvh_nodes = want_bvh ? reinterpret_cast<const uint4 *>(base + off_nodes) : nullptr;
+    for (int a = 0; a < 3; a++) {
+        // origin - 2^23 step, rounded once more to binary32 (that rounding is part of bvh_slack)
+        c->dscene.bvh_base[a] = (float)((double)qframe.origin[a] - 8388608.0 * (double)qframe.step[a]);
+        c->dscene.bvh_step[a] = qframe.step[a];
+    }
+    // 2^-24 (|origin| + 260 extent) bounds what the roundings of a dequantised plane add up to (rt_bvh_device.hpp)
+    c->dscene.bvh_slack = round_up((double)qframe.origin_max * 1.2e-7 + (double)qframe.extent_max * 3.1e-5);
+    c->dscene.bvh_sphere_floor = sphere_floor;
     c->dscene.bvh_sphere_geom = want_bvh ? reinterpret_cast<const float4 *>(base + off_bsph) : nullptr;
     c->dscene.bvh_sphere_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_bsid) : nullptr;
     c->dscene.bvh_tri_isect = want_bvh ? reinterpret_cast<const float4 *>(base + off_btri) : nullptr;
