@@ -166,7 +166,12 @@ def load():
             "raytracer_amd: %s is missing; build it with `make -C raytracer_amd/csrc` "
             "(there is no fallback path)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    # RTMI_HOST_ONLY=1: a sanitizer build of the host side alone (raytracer_amd/csrc/Makefile, host-asan /
+    # host-tsan) exports no device entry points; only what it has is bound
+    host_only = os.environ.get("RTMI_HOST_ONLY") == "1"
     for name, (res, args) in PROTOTYPES.items():
+        if host_only and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

@@ -8,7 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# ORACLE_LIBRARY selects another build of the same file (the sanitizer build, oracle/Makefile target asan)
+LIB_PATH = os.environ.get("ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 N_COUNTERS = 16
 COUNTER_NAMES = [
