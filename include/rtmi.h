@@ -226,6 +226,16 @@ RTMI_API void *rtmi_accum_device_ptr(rtmi_ctx *ctx);
  * does NOT mean HIP's null stream, which is named by the runtime's hipStreamLegacy handle. */
 RTMI_API int rtmi_set_stream(rtmi_ctx *ctx, void *hip_stream);
 RTMI_API int rtmi_synchronize(rtmi_ctx *ctx);
+
+/* Several GPUs in one process (no counterpart in the reference, which drives one GPU): the number of HIP
+ * devices, and the sum of the accumulation images of n contexts, one per GPU and all of one extent, onto
+ * contexts[root] by one RCCL reduce over xGMI, enqueued on every context's stream without a host
+ * synchronisation.  Each context renders a disjoint frame range from a cleared image (rtmi_clear_accum,
+ * rtmi_render_frames; a frame's contribution depends only on pixel, frame index, scene and camera,
+ * RT.comp:462); after the sum, rtmi_resolve_output(root, total_frames) restores alpha and rebuilds the
+ * display image.  RCCL is opened at run time, and only when n > 1. */
+RTMI_API int rtmi_device_count(void);
+RTMI_API int rtmi_reduce_accum(rtmi_ctx *const *contexts, uint32_t n, uint32_t root);
 /* Device time of the most recent render call, from HIP events recorded around its kernels on the
  * stream they ran on; waits for them to complete. */
 RTMI_API int rtmi_last_render_ms(rtmi_ctx *ctx, float *ms);

@@ -118,6 +118,8 @@ PROTOTYPES = {
     "rtmi_accum_device_ptr": (C.c_void_p, [_ctx]),
     "rtmi_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "rtmi_synchronize": (C.c_int, [_ctx]),
+    "rtmi_device_count": (C.c_int, []),
+    "rtmi_reduce_accum": (C.c_int, [C.POINTER(_ctx), C.c_uint32, C.c_uint32]),
     "rtmi_last_render_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
     "rtmi_timing_reset": (C.c_int, [_ctx, C.c_int]),
     "rtmi_timing_read": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -8,6 +8,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtmi.h"
@@ -27,6 +28,7 @@ struct Options {
     int move_at = -1;  // frame at which the W key is held for one frame (exercises reset-on-move)
     std::string scene, script, resume, checkpoint;
     int device = 0;
+    int gpus = 0;  // > 0: frames split over GPUs 0 .. gpus-1 of this node, images summed with RCCL (implies --batch)
     int quad_rule = 0;
 };
 
@@ -35,6 +37,7 @@ void Usage()
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
               "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3|4] [--batch]\n"
               "              [--move-at FRAME] [--device N] [--fan]\n"
+              "              [--gpus N]           static camera: frames 1..N split over GPUs 0..N-1, one RCCL sum at the end\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
               "              [--script FILE]      camera input, one line per run of frames:\n"
               "                                   FRAMES DT KEYS MOUSE_X MOUSE_Y BUTTON2 RESET\n"
@@ -109,6 +112,7 @@ int main(int argc, char **argv)
         else if (a == "--batch") o.batch = true;
         else if (a == "--move-at" && need(1)) o.move_at = std::atoi(argv[++i]);
         else if (a == "--device" && need(1)) o.device = std::atoi(argv[++i]);
+        else if (a == "--gpus" && need(1)) { o.gpus = std::atoi(argv[++i]); o.batch = true; }
         else if (a == "--fan") o.quad_rule = 1;
         else if (a == "--scene" && need(1)) o.scene = argv[++i];
         else if (a == "--script" && need(1)) o.script = argv[++i];
@@ -161,12 +165,48 @@ int main(int argc, char **argv)
         return 1;
     }
 
+    // --gpus N: one context per GPU, each set up by a thread of its own (an upload may build hierarchies)
+    std::vector<rtmi_ctx *> group;
+    if (o.gpus > 0) {
+        const int have = rtmi_device_count();
+        if (have < o.gpus) {
+            std::fprintf(stderr, "rtmi_headless: --gpus %d asked for, but only %d device%s visible on this machine\n", o.gpus,
+                         have < 0 ? 0 : have, have == 1 ? " is" : "s are");
+            return 1;
+        }
+        if (!o.resume.empty() || !o.script.empty()) {
+            std::fprintf(stderr, "rtmi_headless: --gpus renders a static camera from frame 1; --resume and --script do not apply\n");
+            return 2;
+        }
+        group.assign((size_t)o.gpus, nullptr);
+        std::vector<int> ok((size_t)o.gpus, 0);
+        std::vector<std::thread> setup;
+        for (int g = 0; g < o.gpus; g++)
+            setup.emplace_back([&, g] {
+                rtmi_ctx *c = nullptr;
+                if (!Check(nullptr, rtmi_create(g, o.width, o.height, &c), "rtmi_create")) return;
+                group[(size_t)g] = c;
+                if (!Check(c, rtmi_set_variant(c, o.variant), "rtmi_set_variant")) return;
+                if (!Check(c, rtmi_upload_scene(c, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
+                           "rtmi_upload_scene"))
+                    return;
+                ok[(size_t)g] = 1;
+            });
+        for (std::thread &t : setup) t.join();
+        for (int g = 0; g < o.gpus; g++)
+            if (!ok[(size_t)g]) return 1;
+    }
+
     rtmi_ctx *ctx = nullptr;
-    if (!Check(nullptr, rtmi_create(o.device, o.width, o.height, &ctx), "rtmi_create")) return 1;
-    if (!Check(ctx, rtmi_set_variant(ctx, o.variant), "rtmi_set_variant")) return 1;
-    if (!Check(ctx, rtmi_upload_scene(ctx, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
-               "rtmi_upload_scene"))
-        return 1;
+    if (!group.empty()) {
+        ctx = group[0];   // the root: holds the sum, is read back and written out
+    } else {
+        if (!Check(nullptr, rtmi_create(o.device, o.width, o.height, &ctx), "rtmi_create")) return 1;
+        if (!Check(ctx, rtmi_set_variant(ctx, o.variant), "rtmi_set_variant")) return 1;
+        if (!Check(ctx, rtmi_upload_scene(ctx, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
+                   "rtmi_upload_scene"))
+            return 1;
+    }
 
     rtmi_frame_data fd;
     rtmi_default_frame_data(&fd);
@@ -187,7 +227,26 @@ int main(int argc, char **argv)
 
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t shown_frame_index = 0, rendered = 0;
-    if (o.batch) {
+    if (!group.empty()) {
+        // Frames 1 .. N in contiguous, balanced ranges, one per GPU, each summed into a cleared image (a frame's
+        // contribution depends only on pixel, frame index, scene and camera: Raytracing.comp:462); then one RCCL
+        // reduce onto GPU 0, which puts alpha back to 1 and rebuilds the display image as sum / N.
+        rtmi_camera_input in{};
+        rtmi_camera_update(&cam, 0.0, &in);
+        rtmi_frame_advance(&fd, &cam, 0);
+        const uint32_t world = (uint32_t)group.size(), q = o.frames / world, rem = o.frames % world;
+        for (uint32_t g = 0; g < world; g++) {
+            const uint32_t n = q + (g < rem ? 1u : 0u), first = 1u + g * q + (g < rem ? g : rem);
+            if (!Check(group[g], rtmi_clear_accum(group[g]), "rtmi_clear_accum")) return 1;
+            if (n && !Check(group[g], rtmi_render_frames(group[g], &fd, first, n), "rtmi_render_frames")) return 1;
+        }
+        if (!Check(ctx, rtmi_reduce_accum(group.data(), world, 0), "rtmi_reduce_accum")) return 1;
+        if (!Check(ctx, rtmi_resolve_output(ctx, o.frames), "rtmi_resolve_output")) return 1;
+        for (uint32_t g = 1; g < world; g++)
+            if (!Check(group[g], rtmi_synchronize(group[g]), "rtmi_synchronize")) return 1;
+        shown_frame_index = o.frames;
+        rendered = o.frames;
+    } else if (o.batch) {
         rtmi_camera_input in{};
         rtmi_camera_update(&cam, 0.0, &in);
         rtmi_frame_advance(&fd, &cam, 0);  // frame_index becomes 1
@@ -221,9 +280,9 @@ int main(int argc, char **argv)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double paths = (double)o.width * o.height * rendered * fd.rays_per_pixel;
     std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"rays_per_pixel\": %u, \"max_bounce\": %u, "
-                "\"seconds\": %.6f, \"mpaths_per_s\": %.3f, \"frame_index\": %u}\n",
+                "\"seconds\": %.6f, \"mpaths_per_s\": %.3f, \"frame_index\": %u, \"gpus\": %d}\n",
                 o.width, o.height, rendered, fd.rays_per_pixel, fd.max_bounce_limit, secs, paths / secs / 1e6,
-                shown_frame_index);
+                shown_frame_index, group.empty() ? 1 : (int)group.size());
 
     if (!o.checkpoint.empty() && !Check(ctx, rtmi_checkpoint_save(ctx, o.checkpoint.c_str(), shown_frame_index), "rtmi_checkpoint_save"))
         return 1;
@@ -245,6 +304,7 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    rtmi_destroy(ctx);
+    if (group.empty()) rtmi_destroy(ctx);
+    for (rtmi_ctx *c : group) rtmi_destroy(c);
     return 0;
 }

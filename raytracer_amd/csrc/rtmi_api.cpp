@@ -4,6 +4,8 @@
 #include "rtmi.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened at run time, when several GPUs are summed
 
 #include <algorithm>
 #include <cmath>
@@ -11,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -917,6 +920,104 @@ int rtmi_reset_counters(rtmi_ctx *c)
     if (!c) return RTMI_ERR_INVALID_ARGUMENT;
     if (int rc = use_device(c)) return rc;
     HIP_TRY(c, hipMemsetAsync(c->counters, 0, RTMI_N_COUNTERS * sizeof(unsigned long long), c->stream));
+    return RTMI_OK;
+}
+
+int rtmi_device_count(void)
+{
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(nullptr, RTMI_ERR_NO_DEVICE, "rtmi_device_count: %s", hipGetErrorString(e));
+    return count;
+}
+
+// RCCL, opened when first needed (a process that renders on one GPU never loads it).
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // communicators are kept for the device list they were made for (making them costs about a second)
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    std::mutex lock;
+    bool Load(std::string &why)
+    {
+        if (handle) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) {
+            why = dlerror();
+            return false;
+        }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(handle, "ncclReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(handle, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) {
+            why = "librccl lacks an expected symbol";
+            dlclose(handle);
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+} g_rccl;
+}  // namespace
+
+// Sum of the accumulation images of n contexts, one per GPU, onto contexts[root]: one RCCL reduce over xGMI,
+// enqueued on every context's stream (no host synchronisation; the root's stream holds the sum once its
+// part of the collective has run).  The partial images must have been rendered from cleared images over
+// disjoint frame ranges (rtmi_clear_accum, then rtmi_render_frames); afterwards rtmi_resolve_output on
+// the root restores alpha and rebuilds the display image.
+int rtmi_reduce_accum(rtmi_ctx *const *contexts, uint32_t n, uint32_t root)
+{
+    if (!contexts || n == 0 || root >= n) return RTMI_ERR_INVALID_ARGUMENT;
+    rtmi_ctx *r = contexts[root];
+    if (!r) return RTMI_ERR_INVALID_ARGUMENT;
+    std::vector<int> devices(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!contexts[i]) return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: context %u is NULL", i);
+        if (contexts[i]->width != r->width || contexts[i]->height != r->height)
+            return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: context %u is %ux%u, the root %ux%u", i, contexts[i]->width,
+                        contexts[i]->height, r->width, r->height);
+        devices[i] = contexts[i]->device;
+        for (uint32_t j = 0; j < i; j++)
+            if (devices[j] == devices[i])
+                return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: contexts %u and %u are on the same GPU (%d)", j, i, devices[i]);
+    }
+    if (n == 1) return RTMI_OK;   // a sum over one image
+    std::lock_guard<std::mutex> guard(g_rccl.lock);
+    std::string why;
+    if (!g_rccl.Load(why)) return fail(r, RTMI_ERR_UNSUPPORTED, "rtmi_reduce_accum: cannot open RCCL: %s", why.c_str());
+    if (g_rccl.devices != devices) {
+        for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
+        g_rccl.comms.assign(n, nullptr);
+        g_rccl.devices.clear();
+        const ncclResult_t rc = g_rccl.CommInitAll(g_rccl.comms.data(), (int)n, devices.data());
+        if (rc != ncclSuccess) {
+            g_rccl.comms.clear();
+            return fail(r, RTMI_ERR_HIP, "rtmi_reduce_accum: ncclCommInitAll: %s", g_rccl.GetErrorString(rc));
+        }
+        g_rccl.devices = devices;
+    }
+    const size_t count = n_pixels(r) * 4;
+    ncclResult_t rc = g_rccl.GroupStart();
+    for (uint32_t i = 0; i < n && rc == ncclSuccess; i++) {
+        if (hipSetDevice(devices[i]) != hipSuccess) rc = ncclUnhandledCudaError;
+        else rc = g_rccl.Reduce(contexts[i]->accum, contexts[i]->accum, count, ncclFloat32, ncclSum, (int)root, g_rccl.comms[i], contexts[i]->stream);
+    }
+    const ncclResult_t rc_end = g_rccl.GroupEnd();
+    if (rc == ncclSuccess) rc = rc_end;
+    if (rc != ncclSuccess) return fail(r, RTMI_ERR_HIP, "rtmi_reduce_accum: %s", g_rccl.GetErrorString(rc));
     return RTMI_OK;
 }
 

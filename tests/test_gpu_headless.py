@@ -82,3 +82,39 @@ def test_scene_file_script_and_snapshots(rtmi, tmp_path):
     script.write_text("2 0.016 - 0 0 0 0\n1 0.25 W 0 0 0 0\n3 0.016 - 0 0 0 0\n")
     info = _run(rtmi, "--scene", str(scene_file), "--script", str(script), "--pose", *POSE)
     assert info["frames"] == 6 and info["frame_index"] == 4          # 1, 2, (moved) 1, 2, 3, 4
+
+
+def test_gpus_option(rtmi, tmp_path):
+    """--gpus N splits the frames over N GPUs and sums the images with RCCL (rtmi_reduce_accum).  One GPU:
+    the same picture as --batch, bit for bit.  More GPUs than the machine has: a clear message.  With two
+    or more GPUs: the two-GPU picture against the one-GPU picture within the tolerance of a re-associated sum."""
+    exe = os.path.join(rtmi.abi.PKG_DIR, "rtmi_headless")
+    have = rtmi.abi.load().rtmi_device_count()
+    assert have >= 1
+    a, b = tmp_path / "a.pfm", tmp_path / "b.pfm"
+    one = _run(rtmi, "--frames", "6", "--rpp", "1", "--bounces", "8", "--pose", *POSE, "--batch", "--pfm", str(a))
+    grp = _run(rtmi, "--frames", "6", "--rpp", "1", "--bounces", "8", "--pose", *POSE, "--gpus", "1", "--pfm", str(b))
+    assert (one["gpus"], grp["gpus"]) == (1, 1) and grp["frame_index"] == 6
+    assert cases.bits_equal(_read_pfm(a), _read_pfm(b))
+    out = subprocess.run([exe, "--size", str(W), str(H), "--gpus", str(have + 1)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "only %d device" % have in out.stderr
+    if have >= 2:
+        c = tmp_path / "c.pfm"
+        two = _run(rtmi, "--frames", "6", "--rpp", "1", "--bounces", "8", "--pose", *POSE, "--gpus", "2", "--pfm", str(c))
+        assert two["gpus"] == 2
+        x, y = _read_pfm(a), _read_pfm(c)
+        assert np.allclose(x, y, rtol=0, atol=6 * 4e-7 * max(1.0, float(x.max())))
+
+
+def test_reduce_accum_argument_checks(rtmi):
+    lib = rtmi.abi.load()
+    import ctypes as C
+    with rtmi.Renderer(16, 8) as r1, rtmi.Renderer(16, 8) as r2, rtmi.Renderer(8, 8) as r3:
+        one = (C.c_void_p * 1)(r1._ctx)
+        assert lib.rtmi_reduce_accum(one, 1, 0) == 0                 # a sum over one image
+        assert lib.rtmi_reduce_accum(one, 1, 1) == rtmi.abi.ERR_INVALID_ARGUMENT
+        same_gpu = (C.c_void_p * 2)(r1._ctx, r2._ctx)
+        assert lib.rtmi_reduce_accum(same_gpu, 2, 0) == rtmi.abi.ERR_INVALID_ARGUMENT
+        assert b"same GPU" in lib.rtmi_last_error(r1._ctx)
+        other_size = (C.c_void_p * 2)(r1._ctx, r3._ctx)
+        assert lib.rtmi_reduce_accum(other_size, 2, 0) == rtmi.abi.ERR_INVALID_ARGUMENT
