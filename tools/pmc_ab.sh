@@ -15,4 +15,4 @@ pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
 pass sq3 SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_IFETCH
 python3 tools/pmc_summary.py $OUT > $OUT.txt
-grep -A40 "k_paths" $OUT.txt | head -45
+grep -A40 "k_paths\|k_stream" $OUT.txt | head -45
