@@ -53,7 +53,7 @@ def build_scene(R, scene_name):
     return (R.sphere_scene() if scene_name == "spheres" else R.reference_scene()), R.BENCH_POSE
 
 
-def cpu_baseline(workload, frames_hint, budget_s):
+def cpu_baseline(workload, frames_hint, budget_s, profile="strict"):
     """Time the oracle on a bounded sample of the workload (same image, fewer frames; for the stress
     scene a coarser image of the same view)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -74,7 +74,7 @@ def cpu_baseline(workload, frames_hint, budget_s):
         sw, sh = 64, 36
         fd = O.frame_data(sw, sh, pos=pose[0], yaw=pose[1], pitch=pose[2], rpp=1, max_bounce=mb, scene=sc)
         t0 = time.perf_counter()
-        O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False)
+        O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False, profile=profile)
         dt = time.perf_counter() - t0
         return {
             "value": sw * sh / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
@@ -86,11 +86,11 @@ def cpu_baseline(workload, frames_hint, budget_s):
     sc = cases.oracle_scene(case)
     fd = cases.oracle_frame_data(case, sc)
     t0 = time.perf_counter()
-    O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False)
+    O.render(fd, sc, 1, 1, n_threads=cores, want_debug=False, profile=profile)
     t1 = time.perf_counter() - t0
     n = max(1, min(frames_hint, int(budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    O.render(fd, sc, 1, n, n_threads=cores, want_debug=False)
+    O.render(fd, sc, 1, n, n_threads=cores, want_debug=False, profile=profile)
     dt = time.perf_counter() - t0
     return {
         "value": w * h * n / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--variant", type=int, default=None, choices=[0, 1, 2, 4],
                     help="0 nested megakernel, 1 regenerating megakernel, 2 classify + wave-cooperative paths (default), "
                          "4 pixel-streaming kernel (hierarchy scenes; default for c5)")
+    ap.add_argument("--profile", default="strict", choices=["strict", "fma"],
+                    help="arithmetic profile: strict (default; every multiply and add rounded separately, the profile the "
+                         "headline number is quoted in) or fma (fused multiply-adds at a fixed list of sites)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--reduce", default="reduce", choices=["reduce", "allreduce"],
@@ -173,7 +176,7 @@ def main():
     fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
     total_frames = frames * world
 
-    renderer = R.Renderer(width, height, device=local_rank, variant=args.variant)
+    renderer = R.Renderer(width, height, device=local_rank, variant=args.variant, profile=args.profile)
     renderer.upload_scene(scene)
     sr = ShardedRenderer(renderer, device)
 
@@ -256,6 +259,7 @@ def main():
                                                       scene.n_meshes, width, height, frames, max_bounce),
             "closest_hit": "hierarchy" if renderer.acceleration() == R.abi.ACCEL_BVH else "exhaustive loops",
             "variant": {0: "megakernel", 1: "regenerate", 2: "compact", 4: "stream"}[args.variant],
+            "arithmetic_profile": renderer.profile(),
             "frames_per_gpu": frames, "total_frames": total_frames,
             "parallelism": "frame-range split x%d + RCCL %s(sum) of float4 accumulation" % (
                 world, "reduce to rank 0" if dst is not None else "all-reduce") if world > 1 else "single GPU",
@@ -286,6 +290,15 @@ def main():
         "msegments_per_s": counters["n_segments"] / (kernel_ms * 1e-3) / 1e6,
         "counters_rank0_launch": counters,
     }
+    if args.profile == "fma":
+        # a fused multiply-add counts as two flops in the algorithmic figure, as the separate multiply and add do;
+        # the sites that are not multiply-add shaped (compares, selects, divisions, the RNG) still issue one
+        # operation per instruction
+        result["roofline"]["note"] = ("fused profile: multiply-add shaped sites issue one v_fma_f32 (2 flops); peak = one "
+                                      "v_fma_f32 per wave64 per 2 cycles per SIMD; frac prices the reference algorithm's "
+                                      "flops, frac_executed the flops the kernels actually perform")
+        for k in ("peak_unfused", "peak_unfused_measured_issue", "frac_executed_of_unfused_peak"):
+            result["roofline"].pop(k)
     if traffic is not None:
         # what the counters saw reach the memory side, at this run's launch time
         result["roofline"]["hbm_gbs_from_traffic"] = traffic / (kernel_ms * 1e-3) / 1e9
@@ -314,7 +327,7 @@ def main():
                     "node and primitive records the walk fetches wherever they are served from",
         })
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds, args.profile)
     if rank == 0:
         print(json.dumps(result))
     sr = None

@@ -130,6 +130,20 @@ typedef enum rtmi_accel {
     RTMI_ACCEL_BVH  = 2
 } rtmi_accel;
 
+/* Arithmetic profile.  STRICT (default): every multiply and add of the shader is one rounded binary32
+ * operation, in the order the shader writes them: what a SPIR-V consumer that does not contract computes.
+ * FMA: the same sequences with a fused multiply-add (one rounding) at a fixed list of sites: the sums of
+ * products of dot, cross, mix, reflect and the matrix-vector products of RT.comp:448-453, the Horner steps
+ * of pow, b*b - 4ac of RaySphere, origin + direction * t, the blend of the shading normals, and the
+ * light / throughput updates of Trace.  RT.comp carries no `precise` qualifier, so a driver's compiler may
+ * contract it this way.  Each profile is deterministic and has its own CPU oracle build; images of the two
+ * differ by rounding only (a hit decided by the last bit may flip).  FMA is 7-8 % faster.
+ * The reference has no counterpart. */
+typedef enum rtmi_profile {
+    RTMI_PROFILE_STRICT = 0,
+    RTMI_PROFILE_FMA    = 1
+} rtmi_profile;
+
 /* Event counters (uint64 each), index = rtmi_counter.  Same events the CPU oracle counts.  With a
  * hierarchy in use, the three test counters count the tests actually made (box tests include the
  * hierarchy's node boxes), which are fewer than the oracle's exhaustive loops make. */
@@ -199,6 +213,12 @@ RTMI_API int rtmi_get_variant(const rtmi_ctx *ctx);
  * the uploaded scene uses: RTMI_ACCEL_NONE or RTMI_ACCEL_BVH. */
 RTMI_API int rtmi_set_acceleration(rtmi_ctx *ctx, int mode);
 RTMI_API int rtmi_get_acceleration(const rtmi_ctx *ctx);
+/* Profile for the NEXT rtmi_upload_scene (default RTMI_PROFILE_STRICT): the upload precomputes each
+ * triangle's AB x AC in the profile's arithmetic, and launches use the kernels of the profile the scene
+ * was uploaded under.  rtmi_get_profile tells which that is (before any upload: the mode set).  The
+ * rtmi_selftest_math / _env_light hooks follow the mode set, rtmi_selftest_closest_hit the uploaded scene. */
+RTMI_API int rtmi_set_profile(rtmi_ctx *ctx, int profile);
+RTMI_API int rtmi_get_profile(const rtmi_ctx *ctx);
 
 /* Accumulation image (binding 5, rgba32f, running SUM not mean; RT.comp:471-479). */
 RTMI_API int rtmi_clear_accum(rtmi_ctx *ctx);

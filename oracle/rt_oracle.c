@@ -101,6 +101,104 @@ static inline float g_smoothstep(float e0, float e1, float x)
 }
 static inline v3 v3_from(const float *p) { return v3_make(p[0], p[1], p[2]); }
 
+/* ---------------------------------------------------------------------------------------------
+ * Arithmetic profile of the SHADER's operations (the host-side camera and loader arithmetic above and
+ * below is not affected).  Default ("strict"): every multiply and add is one rounded operation.  With
+ * -DORC_PROFILE_FMA ("fused", liboracle_fma.so) a fixed list of sites uses fmaf, one rounding: the sums
+ * of products of dot, cross, mix, reflect and the matrix-vector products, the Horner steps of pow,
+ * b*b - 4ac, origin + direction * t, the blend of the shading normals, and light + emission * throughput /
+ * light + sky * throughput.  Raytracing.comp carries no `precise`, so a shader compiler may contract it
+ * like this; fmaf is correctly rounded everywhere, so the fused profile is as reproducible as the strict one.
+ * ------------------------------------------------------------------------------------------ */
+#ifdef ORC_PROFILE_FMA
+#define ORC_FUSED 1
+#else
+#define ORC_FUSED 0
+#endif
+int orc_profile(void) { return ORC_FUSED; }
+
+/* a * b + c at a site the fused profile fuses */
+static inline float sh_mul_add(float a, float b, float c)
+{
+#if ORC_FUSED
+    return fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+static inline float sh_dot(v3 a, v3 b)
+{
+#if ORC_FUSED
+    return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+#else
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+#endif
+}
+static inline v3 sh_cross(v3 a, v3 b)
+{
+#if ORC_FUSED
+    return v3_make(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
+#else
+    return v3_make(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+#endif
+}
+static inline v3 sh_normalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(sh_dot(a, a));
+    return v3_scale(a, inv);
+}
+static inline float sh_mix1(float a, float b, float t)
+{
+#if ORC_FUSED
+    return fmaf(b, t, a * (1.0f - t));
+#else
+    return a * (1.0f - t) + b * t;
+#endif
+}
+static inline v3 sh_mix(v3 a, v3 b, float t)
+{
+    return v3_make(sh_mix1(a.x, b.x, t), sh_mix1(a.y, b.y, t), sh_mix1(a.z, b.z, t));
+}
+/* reflect(I, N) = I - 2 * dot(N, I) * N */
+static inline v3 sh_reflect(v3 i, v3 n)
+{
+    float k = 2.0f * sh_dot(n, i);
+#if ORC_FUSED
+    return v3_make(fmaf(-n.x, k, i.x), fmaf(-n.y, k, i.y), fmaf(-n.z, k, i.z));
+#else
+    return v3_sub(i, v3_scale(n, k));
+#endif
+}
+/* o + d * t */
+static inline v3 sh_along(v3 o, v3 d, float t)
+{
+#if ORC_FUSED
+    return v3_make(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+#else
+    return v3_add(o, v3_scale(d, t));
+#endif
+}
+/* l + a * b, componentwise */
+static inline v3 sh_add_mul(v3 l, v3 a, v3 b)
+{
+#if ORC_FUSED
+    return v3_make(fmaf(a.x, b.x, l.x), fmaf(a.y, b.y, l.y), fmaf(a.z, b.z, l.z));
+#else
+    return v3_add(l, v3_mul(a, b));
+#endif
+}
+/* column-major mat4 times vec4, summed left to right over columns */
+static inline void sh_mat4_mul_vec4(const float m[16], const float v[4], float out[4])
+{
+    for (int r = 0; r < 4; r++) {
+#if ORC_FUSED
+        out[r] = fmaf(m[12 + r], v[3], fmaf(m[8 + r], v[2], fmaf(m[4 + r], v[1], m[0 + r] * v[0])));
+#else
+        out[r] = m[0 + r] * v[0] + m[4 + r] * v[1] + m[8 + r] * v[2] + m[12 + r] * v[3];
+#endif
+    }
+}
+
 /* column-major mat4 times vec4, summed left to right over columns */
 static inline void mat4_mul_vec4(const float m[16], const float v[4], float out[4])
 {
@@ -131,19 +229,23 @@ float orc_log2(float x)
     float f = m - 1.0f;
     float z = f * f;
     float p = 7.0376836292e-2f;
-    p = p * f + -1.1514610310e-1f;
-    p = p * f + 1.1676998740e-1f;
-    p = p * f + -1.2420140846e-1f;
-    p = p * f + 1.4249322787e-1f;
-    p = p * f + -1.6668057665e-1f;
-    p = p * f + 2.0000714765e-1f;
-    p = p * f + -2.4999993993e-1f;
-    p = p * f + 3.3333331174e-1f;
+    p = sh_mul_add(p, f, -1.1514610310e-1f);
+    p = sh_mul_add(p, f, 1.1676998740e-1f);
+    p = sh_mul_add(p, f, -1.2420140846e-1f);
+    p = sh_mul_add(p, f, 1.4249322787e-1f);
+    p = sh_mul_add(p, f, -1.6668057665e-1f);
+    p = sh_mul_add(p, f, 2.0000714765e-1f);
+    p = sh_mul_add(p, f, -2.4999993993e-1f);
+    p = sh_mul_add(p, f, 3.3333331174e-1f);
     float y = (p * f) * z;
     y = y - 0.5f * z;
     /* log2(m) = (f + y) * log2(e), split as log2(e) = 1 + 0.44269504088896340736 */
     float r = y * 0.44269504088896340736f;
+#if ORC_FUSED
+    r = fmaf(f, 0.44269504088896340736f, r);
+#else
     r = r + f * 0.44269504088896340736f;
+#endif
     r = r + y;
     r = r + f;
     r = r + (float)e;
@@ -160,12 +262,12 @@ float orc_exp2(float x)
     float r = x - fl;
     if (r > 0.5f) { n += 1; r = r - 1.0f; }
     float p = 1.535336188319500e-4f;
-    p = p * r + 1.339887440266574e-3f;
-    p = p * r + 9.618437357674640e-3f;
-    p = p * r + 5.550332471162809e-2f;
-    p = p * r + 2.402264791363012e-1f;
-    p = p * r + 6.931472028550421e-1f;
-    p = p * r + 1.0f;
+    p = sh_mul_add(p, r, 1.339887440266574e-3f);
+    p = sh_mul_add(p, r, 9.618437357674640e-3f);
+    p = sh_mul_add(p, r, 5.550332471162809e-2f);
+    p = sh_mul_add(p, r, 2.402264791363012e-1f);
+    p = sh_mul_add(p, r, 6.931472028550421e-1f);
+    p = sh_mul_add(p, r, 1.0f);
     /* scale by 2^n in at most two exact-constant multiplies */
     if (n > 127) { p = p * u2f(0x7F000000u); n -= 127; }          /* 2^127 */
     if (n < -126) { p = p * u2f(0x00800000u); n += 126; }         /* 2^-126 */
@@ -230,19 +332,23 @@ static hit_info ray_sphere(v3 o, v3 d, const orc_sphere *s, counters_t *cn)
     v3 c = v3_from(s->center);
     float radius = s->radius;
     v3 oc = v3_sub(o, c);
-    float a = v3_dot(d, d);
-    float b = 2.0f * v3_dot(oc, d);
-    float cc = v3_dot(oc, oc) - radius * radius;
+    float a = sh_dot(d, d);
+    float b = 2.0f * sh_dot(oc, d);
+    float cc = sh_dot(oc, oc) - radius * radius;
+#if ORC_FUSED
+    float disc = fmaf(b, b, -(4.0f * a * cc));
+#else
     float disc = b * b - 4.0f * a * cc;
+#endif
     if (cn) cn->c[ORC_N_SPHERE_TESTS]++;
     if (disc >= 0.0f) {
         if (cn) cn->c[ORC_N_SPHERE_DISC_GE0]++;
         float t = (-b - sqrtf(disc)) / (2.0f * a);
         if (t > 0.0001f) {
-            v3 p = v3_add(o, v3_scale(d, t));
+            v3 p = sh_along(o, d, t);
             h.hit = 1;
             h.pos = p;
-            h.nrm = v3_normalize(v3_sub(p, c));
+            h.nrm = sh_normalize(v3_sub(p, c));
             h.dist = t;
             h.mat = s->material;
         }
@@ -258,21 +364,27 @@ static hit_info ray_triangle(v3 o, v3 d, const orc_triangle *tr, counters_t *cn)
     v3 p1 = v3_from(tr->p1), p2 = v3_from(tr->p2), p3 = v3_from(tr->p3);
     v3 ab = v3_sub(p2, p1);
     v3 ac = v3_sub(p3, p1);
-    v3 n = v3_cross(ab, ac);
+    v3 n = sh_cross(ab, ac);
     v3 ao = v3_sub(o, p1);
-    v3 dao = v3_cross(ao, d);
-    float det = -v3_dot(d, n);
+    v3 dao = sh_cross(ao, d);
+    float det = -sh_dot(d, n);
     float inv = 1.0f / det;
-    float t = v3_dot(ao, n) * inv;
-    float u = v3_dot(ac, dao) * inv;
-    float v = -v3_dot(ab, dao) * inv;
+    float t = sh_dot(ao, n) * inv;
+    float u = sh_dot(ac, dao) * inv;
+    float v = -sh_dot(ab, dao) * inv;
     float w = 1.0f - u - v;
     if (cn) cn->c[ORC_N_TRI_TESTS]++;
     h.hit = det >= 1e-6f && t >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-    h.pos = v3_add(o, v3_scale(d, t));
+    h.pos = sh_along(o, d, t);
+#if ORC_FUSED
+    v3 n1 = v3_from(tr->n1), n2 = v3_from(tr->n2), n3 = v3_from(tr->n3);
+    v3 bl = v3_make(fmaf(n3.x, v, fmaf(n2.x, u, n1.x * w)), fmaf(n3.y, v, fmaf(n2.y, u, n1.y * w)),
+                    fmaf(n3.z, v, fmaf(n2.z, u, n1.z * w)));
+#else
     v3 bl = v3_add(v3_add(v3_scale(v3_from(tr->n1), w), v3_scale(v3_from(tr->n2), u)),
                    v3_scale(v3_from(tr->n3), v));
-    h.nrm = v3_normalize(bl);
+#endif
+    h.nrm = sh_normalize(bl);
     h.dist = t;
     return h;
 }
@@ -384,11 +496,11 @@ static v3 env_light(const orc_frame_data *fd, v3 d)
     v3 sun_dir = v3_make(fd->sun_dir[0], fd->sun_dir[2], fd->sun_dir[1]);
     v3 ground = v3_from(fd->ground);
     float grad_t = orc_pow(g_smoothstep(0.0f, 0.4f, d.y), 0.35f);
-    v3 grad = v3_mix(horizon, zenith, grad_t);
-    float sun = orc_pow(g_max(0.0f, v3_dot(d, v3_neg(sun_dir))), fd->sun_focus) * fd->sun_intensity;
+    v3 grad = sh_mix(horizon, zenith, grad_t);
+    float sun = orc_pow(g_max(0.0f, sh_dot(d, v3_neg(sun_dir))), fd->sun_focus) * fd->sun_intensity;
     float g2s = g_smoothstep(-0.01f, 0.0f, d.y);
     float mask = (g2s >= 1.0f) ? 1.0f : 0.0f;
-    v3 base = v3_mix(ground, grad, g2s);
+    v3 base = sh_mix(ground, grad, g2s);
     float add = sun * mask;
     return v3_make(base.x + add, base.y + add, base.z + add);
 }
@@ -416,16 +528,16 @@ static v3 trace(const orc_frame_data *fd, v3 o, v3 d, uint32_t *rng,
             cn->c[ORC_N_HIT_BOUNCES]++;
             if (h.prim < fd->sphere_count) cn->c[ORC_N_SPHERE_WINS]++;
             else cn->c[ORC_N_TRI_WINS]++;
-            v3 diffuse = v3_normalize(v3_add(h.nrm, rng_direction(rng)));
-            v3 spec = v3_reflect(d, h.nrm);
+            v3 diffuse = sh_normalize(v3_add(h.nrm, rng_direction(rng)));
+            v3 spec = sh_reflect(d, h.nrm);
             o = h.pos;
-            d = v3_mix(diffuse, spec, h.mat.smoothness);
+            d = sh_mix(diffuse, spec, h.mat.smoothness);
             float e = 1.0f * h.mat.light;
-            light = v3_add(light, v3_make(e * thr.x, e * thr.y, e * thr.z));
+            light = sh_add_mul(light, v3_make(e, e, e), thr);
             thr = v3_mul(thr, v3_from(h.mat.color));
         } else {
             cn->c[ORC_N_ENV_EVALS]++;
-            light = v3_add(light, v3_mul(env_light(fd, d), thr));
+            light = sh_add_mul(light, env_light(fd, d), thr);
             break;
         }
     }
@@ -439,10 +551,10 @@ void orc_primary_ray(const orc_frame_data *fd, uint32_t x, uint32_t y, float o[3
     float cx = ((float)x / width) * 2.0f - 1.0f;
     float cy = ((float)y / height) * 2.0f - 1.0f;
     float cv[4] = { cx, cy, 1.0f, 1.0f }, tgt[4];
-    mat4_mul_vec4(fd->inv_proj, cv, tgt);
-    v3 n = v3_normalize(v3_make(tgt[0] / tgt[3], tgt[1] / tgt[3], tgt[2] / tgt[3]));
+    sh_mat4_mul_vec4(fd->inv_proj, cv, tgt);
+    v3 n = sh_normalize(v3_make(tgt[0] / tgt[3], tgt[1] / tgt[3], tgt[2] / tgt[3]));
     float nv[4] = { n.x, n.y, n.z, 0.0f }, dv[4];
-    mat4_mul_vec4(fd->inv_view, nv, dv);
+    sh_mat4_mul_vec4(fd->inv_view, nv, dv);
     o[0] = fd->cam_pos[0]; o[1] = fd->cam_pos[1]; o[2] = fd->cam_pos[2];
     d[0] = dv[0]; d[1] = dv[1]; d[2] = dv[2];
 }

@@ -78,6 +78,7 @@ enum {
 #define ORC_MISS_ID 0xFFFFFFFFu
 
 size_t   orc_sizeof(int which); /* 0 frame_data, 1 material, 2 sphere, 3 mesh, 4 triangle */
+int      orc_profile(void);      /* 0 strict (liboracle.so), 1 fused multiply-adds at fixed sites (liboracle_fma.so, -DORC_PROFILE_FMA) */
 size_t   orc_frame_data_offset(int field); /* field index in declaration order, 0..16 */
 
 /* RNG: Raytracing.comp:106-112 */

@@ -27,6 +27,10 @@ ACCEL_AUTO = 0
 ACCEL_NONE = 1
 ACCEL_BVH = 2
 
+PROFILE_STRICT = 0
+PROFILE_FMA = 1
+PROFILE_NAMES = {"strict": PROFILE_STRICT, "fma": PROFILE_FMA}
+
 OK = 0
 ERR_INVALID_ARGUMENT = -1
 ERR_NO_DEVICE = -2
@@ -109,6 +113,8 @@ PROTOTYPES = {
     "rtmi_get_variant": (C.c_int, [_ctx]),
     "rtmi_set_acceleration": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_acceleration": (C.c_int, [_ctx]),
+    "rtmi_set_profile": (C.c_int, [_ctx, C.c_int]),
+    "rtmi_get_profile": (C.c_int, [_ctx]),
     "rtmi_clear_accum": (C.c_int, [_ctx]),
     "rtmi_read_accum": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "rtmi_write_accum": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),

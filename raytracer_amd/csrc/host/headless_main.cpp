@@ -30,13 +30,14 @@ struct Options {
     int device = 0;
     int gpus = 0;  // > 0: frames split over GPUs 0 .. gpus-1 of this node, images summed with RCCL (implies --batch)
     int quad_rule = 0;
+    int profile = RTMI_PROFILE_STRICT;  // arithmetic profile (--profile, default from the environment variable RTMI_PROFILE)
 };
 
 void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
               "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3|4] [--batch]\n"
-              "              [--move-at FRAME] [--device N] [--fan]\n"
+              "              [--move-at FRAME] [--device N] [--fan] [--profile strict|fma]\n"
               "              [--gpus N]           static camera: frames 1..N split over GPUs 0..N-1, one RCCL sum at the end\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
               "              [--script FILE]      camera input, one line per run of frames:\n"
@@ -97,6 +98,18 @@ bool Check(rtmi_ctx *ctx, int rc, const char *what)
 int main(int argc, char **argv)
 {
     Options o;
+    auto profile_by_name = [](const std::string &name, int &out) {
+        if (name == "strict") out = RTMI_PROFILE_STRICT;
+        else if (name == "fma") out = RTMI_PROFILE_FMA;
+        else return false;
+        return true;
+    };
+    if (const char *env = std::getenv("RTMI_PROFILE")) {
+        if (*env && !profile_by_name(env, o.profile)) {
+            std::fprintf(stderr, "rtmi_headless: RTMI_PROFILE=%s is neither strict nor fma\n", env);
+            return 2;
+        }
+    }
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](int n) { return i + n < argc; };
@@ -114,6 +127,7 @@ int main(int argc, char **argv)
         else if (a == "--device" && need(1)) o.device = std::atoi(argv[++i]);
         else if (a == "--gpus" && need(1)) { o.gpus = std::atoi(argv[++i]); o.batch = true; }
         else if (a == "--fan") o.quad_rule = 1;
+        else if (a == "--profile" && need(1)) { if (!profile_by_name(argv[++i], o.profile)) { Usage(); return 2; } }
         else if (a == "--scene" && need(1)) o.scene = argv[++i];
         else if (a == "--script" && need(1)) o.script = argv[++i];
         else if (a == "--resume" && need(1)) o.resume = argv[++i];
@@ -187,6 +201,7 @@ int main(int argc, char **argv)
                 if (!Check(nullptr, rtmi_create(g, o.width, o.height, &c), "rtmi_create")) return;
                 group[(size_t)g] = c;
                 if (!Check(c, rtmi_set_variant(c, o.variant), "rtmi_set_variant")) return;
+                if (!Check(c, rtmi_set_profile(c, o.profile), "rtmi_set_profile")) return;
                 if (!Check(c, rtmi_upload_scene(c, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
                            "rtmi_upload_scene"))
                     return;
@@ -203,6 +218,7 @@ int main(int argc, char **argv)
     } else {
         if (!Check(nullptr, rtmi_create(o.device, o.width, o.height, &ctx), "rtmi_create")) return 1;
         if (!Check(ctx, rtmi_set_variant(ctx, o.variant), "rtmi_set_variant")) return 1;
+        if (!Check(ctx, rtmi_set_profile(ctx, o.profile), "rtmi_set_profile")) return 1;
         if (!Check(ctx, rtmi_upload_scene(ctx, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
                    "rtmi_upload_scene"))
             return 1;
@@ -280,9 +296,9 @@ int main(int argc, char **argv)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double paths = (double)o.width * o.height * rendered * fd.rays_per_pixel;
     std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"rays_per_pixel\": %u, \"max_bounce\": %u, "
-                "\"seconds\": %.6f, \"mpaths_per_s\": %.3f, \"frame_index\": %u, \"gpus\": %d}\n",
+                "\"seconds\": %.6f, \"mpaths_per_s\": %.3f, \"frame_index\": %u, \"gpus\": %d, \"profile\": \"%s\"}\n",
                 o.width, o.height, rendered, fd.rays_per_pixel, fd.max_bounce_limit, secs, paths / secs / 1e6,
-                shown_frame_index, group.empty() ? 1 : (int)group.size());
+                shown_frame_index, group.empty() ? 1 : (int)group.size(), rtmi_get_profile(ctx) == RTMI_PROFILE_FMA ? "fma" : "strict");
 
     if (!o.checkpoint.empty() && !Check(ctx, rtmi_checkpoint_save(ctx, o.checkpoint.c_str(), shown_frame_index), "rtmi_checkpoint_save"))
         return 1;

@@ -244,7 +244,9 @@ __device__ __forceinline__ void bvh_sphere(BvhWalk &w, const DeviceScene &sc, ui
     const V3 oc = o - mk(g.x, g.y, g.z);
     const float b = 2.0f * dot(oc, d);
     const float c = dot(oc, oc) - g.w;
-    const float disc = b * b - (4.0f * w.a) * c;
+    float disc;
+    if constexpr (kFused) disc = __builtin_fmaf(b, b, -((4.0f * w.a) * c));
+    else disc = b * b - (4.0f * w.a) * c;
     // with b >= 0 the root (-b - sqrt(disc)) / (2a) is not above zero (or not a number), which the
     // shader's t > 0.0001 rejects: no need to evaluate it
     if (disc >= 0.0f && b < 0.0f) {

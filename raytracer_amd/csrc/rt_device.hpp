@@ -6,6 +6,14 @@
 // -fhip-fp32-correctly-rounded-divide-sqrt); min/max are compare+select with GLSL's operand
 // rule; pow is a fixed polynomial exp2(y*log2(x)).  Under this contract the kernels reproduce a
 // scalar CPU evaluation of the shader bit for bit.
+//
+// Second profile ("fused", -DRT_PROFILE_FMA): the same sequences with a fused multiply-add, one rounding,
+// at a fixed list of sites: the sums of products of dot, cross, mix, reflect and the matrix-vector products,
+// the Horner steps of the pow polynomials, b*b - 4ac of the sphere test, origin + direction * t, the blend of
+// the shading normals, and light + emission * throughput / light + sky * throughput.  fmaf is correctly
+// rounded on the CPU and on gfx950 alike, so kernels and CPU evaluation agree bit for bit within this profile
+// too; results differ from the strict profile's by rounding only.  A vendor's shader compiler is free to
+// contract the shader this way (Raytracing.comp carries no `precise`).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,6 +26,18 @@ namespace rtd {
 constexpr uint32_t kMissId = 0xFFFFFFFFu;
 constexpr float kFltMax = 3.402823466e+38f;
 
+#ifdef RT_PROFILE_FMA
+constexpr bool kFused = true;
+#else
+constexpr bool kFused = false;
+#endif
+// a * b + c at a site the fused profile fuses
+__device__ __forceinline__ float mul_add(float a, float b, float c)
+{
+    if constexpr (kFused) return __builtin_fmaf(a, b, c);
+    else return a * b + c;
+}
+
 struct V3 {
     float x, y, z;
 };
@@ -27,16 +47,39 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y +
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float dot(V3 a, V3 b)
+{
+    if constexpr (kFused) return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+    else return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 __device__ __forceinline__ V3 cross(V3 a, V3 b)
 {
-    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+    if constexpr (kFused)
+        return mk(__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y)));
+    else
+        return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+// o + d * t
+__device__ __forceinline__ V3 along(V3 o, V3 d, float t)
+{
+    if constexpr (kFused) return mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z));
+    else return o + d * t;
+}
+// l + a * b, componentwise
+__device__ __forceinline__ V3 add_mul(V3 l, V3 a, V3 b)
+{
+    if constexpr (kFused) return mk(__builtin_fmaf(a.x, b.x, l.x), __builtin_fmaf(a.y, b.y, l.y), __builtin_fmaf(a.z, b.z, l.z));
+    else return l + a * b;
 }
 // GLSL min/max operand rule: min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x
 __device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
 __device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
-__device__ __forceinline__ float gmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float gmix(float a, float b, float t)
+{
+    if constexpr (kFused) return __builtin_fmaf(b, t, a * (1.0f - t));
+    else return a * (1.0f - t) + b * t;
+}
 __device__ __forceinline__ V3 gmix(V3 a, V3 b, float t)
 {
     return mk(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t));
@@ -100,12 +143,17 @@ __device__ __forceinline__ V3 normalize(V3 a)
 __device__ __forceinline__ V3 reflect(V3 i, V3 n)
 {
     float k = 2.0f * dot(n, i);
-    return i - n * k;
+    if constexpr (kFused) return mk(__builtin_fmaf(-n.x, k, i.x), __builtin_fmaf(-n.y, k, i.y), __builtin_fmaf(-n.z, k, i.z));
+    else return i - n * k;
 }
+// 3 - 2 t and 2 r - 1 in one instruction: doubling is exact, so the fused form rounds the same exact value
+// as the two-operation form does (in both profiles)
+__device__ __forceinline__ float three_minus_twice(float t) { return __builtin_fmaf(-2.0f, t, 3.0f); }
+__device__ __forceinline__ float twice_minus_one(float r) { return __builtin_fmaf(r, 2.0f, -1.0f); }
 __device__ __forceinline__ float smoothstep(float e0, float e1, float x)
 {
     float t = gclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
-    return t * t * (3.0f - 2.0f * t);
+    return t * t * three_minus_twice(t);
 }
 // smoothstep with compile-time edges: the division is by a constant
 __device__ __forceinline__ float smoothstep_const(float e0, float e1, float x)
@@ -116,7 +164,7 @@ __device__ __forceinline__ float smoothstep_const(float e0, float e1, float x)
     if (div_const_admits(num)) q = div_const_rn(num, c, rc);
     else q = num / c;
     const float t = gclamp(q, 0.0f, 1.0f);
-    return t * t * (3.0f - 2.0f * t);
+    return t * t * three_minus_twice(t);
 }
 
 // ---- pow(x, y) = exp2(y * log2(x)) with fixed polynomials (coefficients: the public-domain Cephes
@@ -139,18 +187,19 @@ __device__ __forceinline__ float log2_poly(float x0)
     float f = m - 1.0f;
     float z = f * f;
     float p = 7.0376836292e-2f;
-    p = p * f + -1.1514610310e-1f;
-    p = p * f + 1.1676998740e-1f;
-    p = p * f + -1.2420140846e-1f;
-    p = p * f + 1.4249322787e-1f;
-    p = p * f + -1.6668057665e-1f;
-    p = p * f + 2.0000714765e-1f;
-    p = p * f + -2.4999993993e-1f;
-    p = p * f + 3.3333331174e-1f;
+    p = mul_add(p, f, -1.1514610310e-1f);
+    p = mul_add(p, f, 1.1676998740e-1f);
+    p = mul_add(p, f, -1.2420140846e-1f);
+    p = mul_add(p, f, 1.4249322787e-1f);
+    p = mul_add(p, f, -1.6668057665e-1f);
+    p = mul_add(p, f, 2.0000714765e-1f);
+    p = mul_add(p, f, -2.4999993993e-1f);
+    p = mul_add(p, f, 3.3333331174e-1f);
     float y = (p * f) * z;
-    y = y - 0.5f * z;
+    y = __builtin_fmaf(-0.5f, z, y);   // y - 0.5 z: halving z is exact (z is 0 or at least 2^-48), so one rounding either way
     float r = y * 0.44269504088896340736f;
-    r = r + f * 0.44269504088896340736f;
+    if constexpr (kFused) r = __builtin_fmaf(f, 0.44269504088896340736f, r);
+    else r = r + f * 0.44269504088896340736f;
     r = r + y;
     r = r + f;
     r = r + (float)e;
@@ -172,12 +221,12 @@ __device__ __forceinline__ float exp2_poly(float x0)
     n += up ? 1 : 0;
     r = up ? r - 1.0f : r;
     float p = 1.535336188319500e-4f;
-    p = p * r + 1.339887440266574e-3f;
-    p = p * r + 9.618437357674640e-3f;
-    p = p * r + 5.550332471162809e-2f;
-    p = p * r + 2.402264791363012e-1f;
-    p = p * r + 6.931472028550421e-1f;
-    p = p * r + 1.0f;
+    p = mul_add(p, r, 1.339887440266574e-3f);
+    p = mul_add(p, r, 9.618437357674640e-3f);
+    p = mul_add(p, r, 5.550332471162809e-2f);
+    p = mul_add(p, r, 2.402264791363012e-1f);
+    p = mul_add(p, r, 6.931472028550421e-1f);
+    p = mul_add(p, r, 1.0f);
     const bool hi = n > 127;
     p = hi ? p * __uint_as_float(0x7F000000u) : p;
     n = hi ? n - 127 : n;
@@ -303,7 +352,8 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
             V3 oc = o - mk(g.x, g.y, g.z);
             b = 2.0f * dot(oc, d);
             float c = dot(oc, oc) - g.w;
-            disc = b * b - a4 * c;
+            if constexpr (kFused) disc = __builtin_fmaf(b, b, -(a4 * c));
+            else disc = b * b - a4 * c;
             if (COUNT) {
                 cn.c[0]++;
                 if (disc >= 0.0f) cn.c[1]++;
@@ -388,7 +438,9 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
                 V3 oc = o - mk(g.x, g.y, g.z);
                 float b = 2.0f * dot(oc, d);
                 float c = dot(oc, oc) - g.w;
-                float disc = b * b - a4 * c;
+                float disc;
+                if constexpr (kFused) disc = __builtin_fmaf(b, b, -(a4 * c));
+                else disc = b * b - a4 * c;
                 if (disc >= 0.0f) {
                     float t = (-b - sqrtf(disc)) / a2;
                     if (t > 0.0001f && t < best.t) {
@@ -498,7 +550,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene &sc, uint32_t n_sph
 __device__ __forceinline__ void resolve_hit(const DeviceScene &sc, uint32_t n_spheres, V3 o, V3 d,
                                             const Hit &h, V3 &pos, V3 &nrm)
 {
-    pos = o + d * h.t;
+    pos = along(o, d, h.t);
     if (h.prim < n_spheres) {
         const float4 g = sc.sphere_geom[h.prim];
         nrm = normalize(pos - mk(g.x, g.y, g.z));
@@ -508,7 +560,13 @@ __device__ __forceinline__ void resolve_hit(const DeviceScene &sc, uint32_t n_sp
         const float4 n2 = sc.tri_shade[3 * j + 1];
         const float4 n3 = sc.tri_shade[3 * j + 2];
         const float w = 1.0f - h.u - h.v;
-        V3 bl = mk(n1.x, n1.y, n1.z) * w + mk(n2.x, n2.y, n2.z) * h.u + mk(n3.x, n3.y, n3.z) * h.v;
+        V3 bl;
+        if constexpr (kFused) {
+            bl = mk(__builtin_fmaf(n3.x, h.v, __builtin_fmaf(n2.x, h.u, n1.x * w)), __builtin_fmaf(n3.y, h.v, __builtin_fmaf(n2.y, h.u, n1.y * w)),
+                    __builtin_fmaf(n3.z, h.v, __builtin_fmaf(n2.z, h.u, n1.z * w)));
+        } else {
+            bl = mk(n1.x, n1.y, n1.z) * w + mk(n2.x, n2.y, n2.z) * h.u + mk(n3.x, n3.y, n3.z) * h.v;
+        }
         nrm = normalize(bl);
     }
 }
@@ -548,18 +606,19 @@ __device__ __forceinline__ float log2_poly_normal(float x)
     float f = m - 1.0f;
     float z = f * f;
     float p = 7.0376836292e-2f;
-    p = p * f + -1.1514610310e-1f;
-    p = p * f + 1.1676998740e-1f;
-    p = p * f + -1.2420140846e-1f;
-    p = p * f + 1.4249322787e-1f;
-    p = p * f + -1.6668057665e-1f;
-    p = p * f + 2.0000714765e-1f;
-    p = p * f + -2.4999993993e-1f;
-    p = p * f + 3.3333331174e-1f;
+    p = mul_add(p, f, -1.1514610310e-1f);
+    p = mul_add(p, f, 1.1676998740e-1f);
+    p = mul_add(p, f, -1.2420140846e-1f);
+    p = mul_add(p, f, 1.4249322787e-1f);
+    p = mul_add(p, f, -1.6668057665e-1f);
+    p = mul_add(p, f, 2.0000714765e-1f);
+    p = mul_add(p, f, -2.4999993993e-1f);
+    p = mul_add(p, f, 3.3333331174e-1f);
     float y = (p * f) * z;
-    y = y - 0.5f * z;
+    y = __builtin_fmaf(-0.5f, z, y);   // y - 0.5 z: halving z is exact (z is 0 or at least 2^-48), so one rounding either way
     float r = y * 0.44269504088896340736f;
-    r = r + f * 0.44269504088896340736f;
+    if constexpr (kFused) r = __builtin_fmaf(f, 0.44269504088896340736f, r);
+    else r = r + f * 0.44269504088896340736f;
     r = r + y;
     r = r + f;
     r = r + (float)e;
@@ -575,12 +634,12 @@ __device__ __forceinline__ float exp2_poly_normal(float x)
     n += up ? 1 : 0;
     r = up ? r - 1.0f : r;
     float p = 1.535336188319500e-4f;
-    p = p * r + 1.339887440266574e-3f;
-    p = p * r + 9.618437357674640e-3f;
-    p = p * r + 5.550332471162809e-2f;
-    p = p * r + 2.402264791363012e-1f;
-    p = p * r + 6.931472028550421e-1f;
-    p = p * r + 1.0f;
+    p = mul_add(p, r, 1.339887440266574e-3f);
+    p = mul_add(p, r, 9.618437357674640e-3f);
+    p = mul_add(p, r, 5.550332471162809e-2f);
+    p = mul_add(p, r, 2.402264791363012e-1f);
+    p = mul_add(p, r, 6.931472028550421e-1f);
+    p = mul_add(p, r, 1.0f);
     return p * __uint_as_float((uint32_t)(n + 127) << 23);   // -125 <= n <= 127
 }
 
@@ -656,15 +715,15 @@ __device__ __forceinline__ void bounce(const DeviceScene &sc, uint32_t n_spheres
     resolve_hit(sc, n_spheres, o, d, h, pos, nrm);
     const float4 m0 = sc.materials[2 * h.mat + 0];
     const float smooth = sc.materials[2 * h.mat + 1].x;
-    float rx = rng_next(rng) * 2.0f - 1.0f;
-    float ry = rng_next(rng) * 2.0f - 1.0f;
-    float rz = rng_next(rng) * 2.0f - 1.0f;
+    float rx = twice_minus_one(rng_next(rng));
+    float ry = twice_minus_one(rng_next(rng));
+    float rz = twice_minus_one(rng_next(rng));
     V3 diffuse = normalize(nrm + mk(rx, ry, rz));
     V3 spec = reflect(d, nrm);
     o = pos;
     d = gmix(diffuse, spec, smooth);
     float e = 1.0f * m0.w;
-    light = light + mk(e * thr.x, e * thr.y, e * thr.z);
+    light = add_mul(light, mk(e, e, e), thr);
     thr = thr * mk(m0.x, m0.y, m0.z);
 }
 

@@ -55,18 +55,23 @@ __device__ __forceinline__ PixelSetup pixel_setup_xy(const RenderParams &p, uint
     s.y = y;
     s.in_range = in_range;
     const float fw = p.window_w, fh = p.window_h;
-    const float cx = ((float)x / fw) * 2.0f - 1.0f;
-    const float cy = ((float)y / fh) * 2.0f - 1.0f;
+    const float cx = twice_minus_one((float)x / fw);
+    const float cy = twice_minus_one((float)y / fh);
     const float *ip = p.inv_proj;
-    float tx = ip[0] * cx + ip[4] * cy + ip[8] * 1.0f + ip[12] * 1.0f;
-    float ty = ip[1] * cx + ip[5] * cy + ip[9] * 1.0f + ip[13] * 1.0f;
-    float tz = ip[2] * cx + ip[6] * cy + ip[10] * 1.0f + ip[14] * 1.0f;
-    float tw = ip[3] * cx + ip[7] * cy + ip[11] * 1.0f + ip[15] * 1.0f;
+    // matrix times (cx, cy, 1, 1) and times (n, 0), columns summed left to right
+    auto row4 = [](float m0, float m1, float m2, float m3, float v0, float v1, float v2, float v3) {
+        if constexpr (kFused) return __builtin_fmaf(m3, v3, __builtin_fmaf(m2, v2, __builtin_fmaf(m1, v1, m0 * v0)));
+        else return m0 * v0 + m1 * v1 + m2 * v2 + m3 * v3;
+    };
+    float tx = row4(ip[0], ip[4], ip[8], ip[12], cx, cy, 1.0f, 1.0f);
+    float ty = row4(ip[1], ip[5], ip[9], ip[13], cx, cy, 1.0f, 1.0f);
+    float tz = row4(ip[2], ip[6], ip[10], ip[14], cx, cy, 1.0f, 1.0f);
+    float tw = row4(ip[3], ip[7], ip[11], ip[15], cx, cy, 1.0f, 1.0f);
     V3 n = normalize(mk(tx / tw, ty / tw, tz / tw));
     const float *iv = p.inv_view;
-    s.dir.x = iv[0] * n.x + iv[4] * n.y + iv[8] * n.z + iv[12] * 0.0f;
-    s.dir.y = iv[1] * n.x + iv[5] * n.y + iv[9] * n.z + iv[13] * 0.0f;
-    s.dir.z = iv[2] * n.x + iv[6] * n.y + iv[10] * n.z + iv[14] * 0.0f;
+    s.dir.x = row4(iv[0], iv[4], iv[8], iv[12], n.x, n.y, n.z, 0.0f);
+    s.dir.y = row4(iv[1], iv[5], iv[9], iv[13], n.x, n.y, n.z, 0.0f);
+    s.dir.z = row4(iv[2], iv[6], iv[10], iv[14], n.x, n.y, n.z, 0.0f);
     s.origin = mk(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
     s.lin = (float)x + fw * (float)y;
     return s;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
                         bounce(sc, nS, h, o, d, light, thr, rng);
                     } else {
                         if (VALIDATE) cn.c[7]++;
-                        light = light + env_light(sky, d) * thr;
+                        light = add_mul(light, env_light(sky, d), thr);
                         break;
                     }
                 }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
             path_done = i >= p.max_bounce;
         } else {
             if (VALIDATE) cn.c[7]++;
-            light = light + env_light(sky, d) * thr;
+            light = add_mul(light, env_light(sky, d), thr);
             // a path whose primary ray leaves the scene: 0 + sky * 1, the same for every sample and frame
             if (very_first) p.primary[(size_t)s.y * p.width + s.x] = make_float4(light.x, light.y, light.z, __uint_as_float(kMissId));
             path_done = true;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                 path_done = i >= p.max_bounce;
             } else {
                 if (VALIDATE) cn.c[7]++;
-                light = light + env_light(sky, d) * thr;
+                light = add_mul(light, env_light(sky, d), thr);
                 path_done = true;
             }
             if (path_done) {
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_from_primary(const RenderPara
             i++;
             path_done = i >= p.max_bounce;
         } else {
-            light = light + env_light(sky, d) * thr;
+            light = add_mul(light, env_light(sky, d), thr);
             path_done = true;
         }
         if (path_done) {
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
     if (sky_pixel) {
         const Sky sky = make_sky(p);
         // Trace(): incomingLight = 0 + env * rayColor(1,1,1), Raytracing.comp:410-411, 434
-        const V3 light = mk(0.0f, 0.0f, 0.0f) + env_light(sky, s.dir) * mk(1.0f, 1.0f, 1.0f);
+        const V3 light = add_mul(mk(0.0f, 0.0f, 0.0f), env_light(sky, s.dir), mk(1.0f, 1.0f, 1.0f));
         if (STORE) p.primary[(size_t)s.y * p.width + s.x] = make_float4(light.x, light.y, light.z, __uint_as_float(kMissId));
         V3 frame_light = mk(0.0f, 0.0f, 0.0f);
         for (uint32_t k = 0; k < p.rays_per_pixel; k++) frame_light = frame_light + light;
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, 
 
 }  // namespace
 
-hipError_t rt_launch_selftest_hit(const DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
+hipError_t RT_SYM(rt_launch_selftest_hit)(const DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream)
 {
     const dim3 grid((unsigned)((n + kBlockThreads - 1) / kBlockThreads), 1, 1);
@@ -854,7 +859,7 @@ hipError_t rt_launch_selftest_hit(const DeviceScene &sc, bool use_bvh, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t rt_launch_selftest_env(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out, hipStream_t stream)
+hipError_t RT_SYM(rt_launch_selftest_env)(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out, hipStream_t stream)
 {
     const size_t per_group = wave_form ? 43u : 64u;
     const dim3 grid((unsigned)((n + per_group - 1) / per_group), 1, 1);
@@ -862,7 +867,7 @@ hipError_t rt_launch_selftest_env(const RenderParams &p, const float *dirs, size
     return hipGetLastError();
 }
 
-const char *rt_kernel_name(int variant)
+const char *RT_SYM(rt_kernel_name)(int variant)
 {
     switch (variant) {
     case 0: return "k_megakernel";
@@ -873,7 +878,7 @@ const char *rt_kernel_name(int variant)
     }
 }
 
-hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)
+hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)
 {
     if (p.width == 0 || p.height == 0 || p.n_frames == 0) return hipErrorInvalidValue;
     const dim3 grid((p.width + kTile - 1) / kTile, (p.height + kTile - 1) / kTile, 1);
@@ -963,20 +968,20 @@ hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, h
     return hipGetLastError();
 }
 
-hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream)
+hipError_t RT_SYM(rt_launch_resolve)(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream)
 {
     const dim3 grid((n_pixels + kBlockThreads - 1) / kBlockThreads, 1, 1);
     hipLaunchKernelGGL(k_resolve, grid, dim3(kBlockThreads, 1, 1), 0, stream, accum, out, n_pixels, divisor);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_selftest_exhaustive(int op, float c, unsigned long long *out, hipStream_t stream)
+hipError_t RT_SYM(rt_launch_selftest_exhaustive)(int op, float c, unsigned long long *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_selftest_exhaustive, dim3((1u << 24) / kBlockThreads, 1, 1), dim3(kBlockThreads, 1, 1), 0, stream, op, c, out);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream)
+hipError_t RT_SYM(rt_launch_selftest)(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream)
 {
     const dim3 grid((unsigned)((n + kBlockThreads - 1) / kBlockThreads), 1, 1);
     hipLaunchKernelGGL(k_selftest, grid, dim3(kBlockThreads, 1, 1), 0, stream, op, x, y, out, n);

@@ -42,17 +42,32 @@ struct RenderParams {
     uint32_t *primary_mat;
 };
 
-const char *rt_kernel_name(int variant);
 // What a variant-2 launch does with the primary-segment cache
 enum RtCacheUse {
     RT_CACHE_NONE = 0,   // evaluate every pixel's primary segment, keep nothing
     RT_CACHE_STORE = 1,  // evaluate it and store it (also leaves hit_list / hit_count for later launches)
     RT_CACHE_LOAD = 2    // no classification: sky pixels add their stored radiance, paths start from the stored hits
 };
-hipError_t rt_launch_render(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache = RT_CACHE_NONE);
-hipError_t rt_launch_resolve(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);
-hipError_t rt_launch_selftest_hit(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
-                                  const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream);
-hipError_t rt_launch_selftest_env(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out, hipStream_t stream);
-hipError_t rt_launch_selftest_exhaustive(int op, float c, unsigned long long *out, hipStream_t stream);
-hipError_t rt_launch_selftest(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);
+
+// The launchers exist once per arithmetic profile: rt_kernels.hip is compiled twice, plainly (strict profile,
+// names as written) and with -DRT_PROFILE_FMA (fused profile, names with the suffix _fma).
+#define RT_DECLARE_LAUNCHERS(S)                                                                                                       \
+    const char *rt_kernel_name##S(int variant);                                                                                       \
+    hipError_t rt_launch_render##S(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache);          \
+    hipError_t rt_launch_resolve##S(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);              \
+    hipError_t rt_launch_selftest_hit##S(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes,             \
+                                         const float *origins, const float *dirs, size_t n, float *t_out, uint32_t *prim_out,         \
+                                         hipStream_t stream);                                                                         \
+    hipError_t rt_launch_selftest_env##S(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out,           \
+                                         hipStream_t stream);                                                                         \
+    hipError_t rt_launch_selftest_exhaustive##S(int op, float c, unsigned long long *out, hipStream_t stream);                        \
+    hipError_t rt_launch_selftest##S(int op, const float *x, const float *y, float *out, size_t n, hipStream_t stream);
+RT_DECLARE_LAUNCHERS()
+RT_DECLARE_LAUNCHERS(_fma)
+#undef RT_DECLARE_LAUNCHERS
+
+#ifdef RT_PROFILE_FMA
+#define RT_SYM(name) name##_fma
+#else
+#define RT_SYM(name) name
+#endif

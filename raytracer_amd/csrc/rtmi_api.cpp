@@ -75,6 +75,8 @@ struct rtmi_ctx {
     rtd::DeviceScene dscene{};
     int accel_mode = RTMI_ACCEL_AUTO;  // applied by the next rtmi_upload_scene
     bool bvh_active = false;           // the uploaded scene carries hierarchies and the kernels use them
+    int profile_mode = RTMI_PROFILE_STRICT;  // applied by the next rtmi_upload_scene
+    bool fused = false;                // the uploaded scene was prepared for, and is rendered by, the fused profile
     std::vector<rtmi_mesh> host_meshes;  // kept for range checks against frame data
 };
 
@@ -250,6 +252,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     // Hierarchies: one over all spheres, one per mesh over that mesh's triangle range.  The boxes are
     // the primitives' exact bounds (rounded outward); the margins that make skipping a box safe are
     // applied by the traversal, relative to each ray.
+    const bool fused = c->profile_mode == RTMI_PROFILE_FMA;
     const bool want_bvh = c->accel_mode == RTMI_ACCEL_BVH ||
                           (c->accel_mode == RTMI_ACCEL_AUTO && (uint64_t)nS + nT > kAutoBvhThreshold);
     std::vector<rtmi::BvhNode> nodes;
@@ -422,9 +425,16 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
             ab[a] = t.p2[a] - t.p1[a];
             ac[a] = t.p3[a] - t.p1[a];
         }
-        n[0] = ab[1] * ac[2] - ac[1] * ab[2];
-        n[1] = ab[2] * ac[0] - ac[2] * ab[0];
-        n[2] = ab[0] * ac[1] - ac[0] * ab[1];
+        if (fused) {
+            // the fused profile's cross product: one product rounded, the other fused into the difference
+            n[0] = std::fmaf(ab[1], ac[2], -(ac[1] * ab[2]));
+            n[1] = std::fmaf(ab[2], ac[0], -(ac[2] * ab[0]));
+            n[2] = std::fmaf(ab[0], ac[1], -(ac[0] * ab[1]));
+        } else {
+            n[0] = ab[1] * ac[2] - ac[1] * ab[2];
+            n[1] = ab[2] * ac[0] - ac[2] * ab[0];
+            n[2] = ab[0] * ac[1] - ac[0] * ab[1];
+        }
         float *d = tri + 16 * (size_t)j;
         for (int a = 0; a < 3; a++) {
             d[0 + a] = t.p1[a];
@@ -500,6 +510,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->dscene.bvh_mesh_root = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_mroot) : nullptr;
     c->dscene.bvh_sphere_root = sphere_root;
     c->bvh_active = want_bvh;
+    c->fused = fused;
     c->dscene.n_spheres = nS;
     c->dscene.n_triangles = nT;
     c->dscene.n_meshes = nM;
@@ -650,7 +661,8 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
             return fail(c, RTMI_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
         }
     }
-    hipError_t e = rt_launch_render(variant, c->validate, p, c->stream, cache);
+    hipError_t e = c->fused ? rt_launch_render_fma(variant, c->validate, p, c->stream, cache)
+                           : rt_launch_render(variant, c->validate, p, c->stream, cache);
     if (e != hipSuccess) {
         drop_store();
         return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));
@@ -715,6 +727,21 @@ int rtmi_set_acceleration(rtmi_ctx *c, int mode)
 }
 
 int rtmi_get_acceleration(const rtmi_ctx *c) { return c ? (c->bvh_active ? RTMI_ACCEL_BVH : RTMI_ACCEL_NONE) : RTMI_ERR_INVALID_ARGUMENT; }
+
+int rtmi_set_profile(rtmi_ctx *c, int profile)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (profile != RTMI_PROFILE_STRICT && profile != RTMI_PROFILE_FMA)
+        return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_set_profile: profile %d not available", profile);
+    c->profile_mode = profile;
+    return RTMI_OK;
+}
+
+int rtmi_get_profile(const rtmi_ctx *c)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    return c->has_scene ? (c->fused ? RTMI_PROFILE_FMA : RTMI_PROFILE_STRICT) : c->profile_mode;
+}
 
 int rtmi_clear_accum(rtmi_ctx *c)
 {
@@ -1035,7 +1062,7 @@ int rtmi_selftest_math(rtmi_ctx *c, int op, const float *x, const float *y, floa
     if (e == hipSuccess && y) e = hipMalloc(&dy, n * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && y) e = hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = rt_launch_selftest(op, dx, dy, dout, n, c->stream);
+    if (e == hipSuccess) e = c->profile_mode == RTMI_PROFILE_FMA ? rt_launch_selftest_fma(op, dx, dy, dout, n, c->stream) : rt_launch_selftest(op, dx, dy, dout, n, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_math: %s", hipGetErrorString(e));
@@ -1060,7 +1087,8 @@ int rtmi_selftest_env_light(rtmi_ctx *c, const rtmi_frame_data *fd, const float 
                     hipGetErrorString(e));
     int rc = RTMI_OK;
     e = hipMemcpyAsync(dbuf, directions, n * 12, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = rt_launch_selftest_env(p, dbuf, n, wave_form != 0, dbuf + 3 * n, c->stream);
+    if (e == hipSuccess) e = c->profile_mode == RTMI_PROFILE_FMA ? rt_launch_selftest_env_fma(p, dbuf, n, wave_form != 0, dbuf + 3 * n, c->stream)
+                                                             : rt_launch_selftest_env(p, dbuf, n, wave_form != 0, dbuf + 3 * n, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, dbuf + 3 * n, n * 12, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_env_light: %s", hipGetErrorString(e));
@@ -1108,7 +1136,8 @@ int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh
     uint32_t *d_p = reinterpret_cast<uint32_t *>(dbuf + 7 * n);
     if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = rt_launch_selftest_hit(c->dscene, c->bvh_active, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream);
+    if (e == hipSuccess) e = c->fused ? rt_launch_selftest_hit_fma(c->dscene, c->bvh_active, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream)
+                                        : rt_launch_selftest_hit(c->dscene, c->bvh_active, sphere_number, mesh_number, d_o, d_d, n, d_t, d_p, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(prim_out, d_p, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -203,7 +203,9 @@ def make_frame_data(width, height, scene=None, pose=DEFAULT_POSE, rays_per_pixel
 class Renderer:
     """One context = one GPU, one image extent (rtmi_create ... rtmi_destroy)."""
 
-    def __init__(self, width, height, device=0, variant=abi.VARIANT_AUTO):
+    def __init__(self, width, height, device=0, variant=abi.VARIANT_AUTO, profile=None):
+        """profile: "strict" (default) or "fma", the arithmetic profile scenes are uploaded and rendered
+        under (rtmi_set_profile); None takes it from the environment variable RTMI_PROFILE."""
         self._lib = abi.load()
         self._ctx = C.c_void_p()
         self.width, self.height = int(width), int(height)
@@ -213,6 +215,9 @@ class Renderer:
             self._ctx = None
             raise RtmiError(rc, msg.decode() if msg else "rtmi_create")
         self.set_variant(variant)
+        if profile is None:
+            profile = os.environ.get("RTMI_PROFILE") or "strict"
+        self.set_profile(profile)
 
     def _check(self, rc):
         if rc < 0:
@@ -239,6 +244,19 @@ class Renderer:
 
     def set_variant(self, variant):
         self._check(self._lib.rtmi_set_variant(self._ctx, variant))
+
+    def set_profile(self, profile):
+        """"strict" / "fma" (or abi.PROFILE_*) for the next upload_scene."""
+        if isinstance(profile, str):
+            if profile not in abi.PROFILE_NAMES:
+                raise ValueError("unknown arithmetic profile %r" % (profile,))
+            profile = abi.PROFILE_NAMES[profile]
+        self._check(self._lib.rtmi_set_profile(self._ctx, profile))
+
+    def profile(self):
+        """Name of the profile the uploaded scene is rendered under (before an upload: the one set)."""
+        v = self._check(self._lib.rtmi_get_profile(self._ctx))
+        return "fma" if v == abi.PROFILE_FMA else "strict"
 
     def set_acceleration(self, mode):
         """abi.ACCEL_AUTO / ACCEL_NONE / ACCEL_BVH for the next upload_scene."""

@@ -65,18 +65,20 @@ def product_frame_data(case, scene):
     return R.make_frame_data(w, h, scene, case["pose"], case["rpp"], case["max_bounce"])
 
 
-def run_oracle(case, n_threads=0):
+def run_oracle(case, n_threads=0, profile=None):
     sc = oracle_scene(case)
     fd = oracle_frame_data(case, sc)
-    return O.render(fd, sc, case["first"], case["n"], accum=seed_accum(case), n_threads=n_threads)
+    return O.render(fd, sc, case["first"], case["n"], accum=seed_accum(case), n_threads=n_threads, profile=profile)
 
 
-def golden_path(name):
-    return os.path.join(GOLDEN_DIR, name + ".npz")
+def golden_path(name, profile=None):
+    """Fixture of an arithmetic profile ("strict", "fma"; None = the default of oracle_lib)."""
+    profile = profile or O.DEFAULT_PROFILE
+    return os.path.join(GOLDEN_DIR, name + ("_fma" if profile == "fma" else "") + ".npz")
 
 
-def load_golden(name):
-    with np.load(golden_path(name), allow_pickle=False) as z:
+def load_golden(name, profile=None):
+    with np.load(golden_path(name, profile), allow_pickle=False) as z:
         out = {k: z[k] for k in z.files}
     out["counters"] = dict(zip(O.COUNTER_NAMES, (int(v) for v in out.pop("counter_values"))))
     return out

@@ -22,14 +22,17 @@ import oracle_lib as O  # noqa: E402
 
 def main():
     O.build()
-    for name, case in cases.CASES.items():
-        r = cases.run_oracle(case)
-        np.savez_compressed(
-            cases.golden_path(name),
-            accum=r["accum"], rgba8=r["rgba8"], prim_id=r["prim_id"], chain_hash=r["chain_hash"],
-            rng_state=r["rng_state"],
-            counter_values=np.array([r["counters"][k] for k in O.COUNTER_NAMES], dtype=np.uint64))
-        print(name, os.path.getsize(cases.golden_path(name)), "bytes", r["counters"])
+    # one set per arithmetic profile: NAME.npz (strict) and NAME_fma.npz (fused multiply-adds at fixed sites)
+    for profile in ("strict", "fma"):
+        for name, case in cases.CASES.items():
+            r = cases.run_oracle(case, profile=profile)
+            path = cases.golden_path(name, profile)
+            np.savez_compressed(
+                path,
+                accum=r["accum"], rgba8=r["rgba8"], prim_id=r["prim_id"], chain_hash=r["chain_hash"],
+                rng_state=r["rng_state"],
+                counter_values=np.array([r["counters"][k] for k in O.COUNTER_NAMES], dtype=np.uint64))
+            print(profile, name, os.path.getsize(path), "bytes", r["counters"])
 
 
 if __name__ == "__main__":

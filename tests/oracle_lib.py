@@ -10,6 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 # ORACLE_LIBRARY selects another build of the same file (the sanitizer build, oracle/Makefile target asan)
 LIB_PATH = os.environ.get("ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")
+# The fused arithmetic profile is a second build of the same file; RTMI_PROFILE=fma makes it the default
+# of lib() / render() / closest_hit(), as it makes "fma" the default profile of raytracer_amd.Renderer.
+FMA_LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_fma.so")
+DEFAULT_PROFILE = os.environ.get("RTMI_PROFILE") or "strict"
 
 N_COUNTERS = 16
 COUNTER_NAMES = [
@@ -51,23 +55,27 @@ class FrameData(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or any(
-            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("rt_oracle.c", "rt_oracle.h", "Makefile")):
+    if force or any(not os.path.exists(path) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(path)
+            for f in ("rt_oracle.c", "rt_oracle.h", "Makefile")) for path in (LIB_PATH, FMA_LIB_PATH)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(profile=None):
+    """The oracle library of an arithmetic profile ("strict" or "fma"; None = DEFAULT_PROFILE)."""
+    profile = profile or DEFAULT_PROFILE
+    if profile in _libs:
+        return _libs[profile]
+    if profile not in ("strict", "fma"):
+        raise ValueError("unknown arithmetic profile %r" % (profile,))
+    path = FMA_LIB_PATH if profile == "fma" else LIB_PATH
+    if not os.path.exists(path):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     f3 = C.POINTER(C.c_float)
     L.orc_sizeof.restype = C.c_size_t
     L.orc_sizeof.argtypes = [C.c_int]
@@ -118,17 +126,21 @@ def lib():
     L.orc_closest_hit.restype = None
     L.orc_closest_hit.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Sphere), C.POINTER(Triangle), C.POINTER(Mesh),
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    _lib = L
+    L.orc_profile.restype = C.c_int
+    L.orc_profile.argtypes = []
+    if L.orc_profile() != (1 if profile == "fma" else 0):
+        raise RuntimeError("%s was not built for the %s profile" % (path, profile))
+    _libs[profile] = L
     return L
 
 
-def closest_hit(scene, origins, directions, sphere_count=None, mesh_count=None):
+def closest_hit(scene, origins, directions, sphere_count=None, mesh_count=None, profile=None):
     """(t, prim_id) per ray, rays as [n, 3] float32 arrays."""
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
     t = np.empty(len(o), dtype=np.float32)
     prim = np.empty(len(o), dtype=np.uint32)
-    lib().orc_closest_hit(scene.n_spheres if sphere_count is None else sphere_count,
+    lib(profile).orc_closest_hit(scene.n_spheres if sphere_count is None else sphere_count,
                           scene.n_meshes.value if mesh_count is None else mesh_count,
                           scene.spheres, scene.tris, scene.meshes, o.ctypes.data, d.ctypes.data, len(o),
                           t.ctypes.data, prim.ctypes.data)
@@ -218,7 +230,7 @@ def frame_data(width, height, pos=(0.0, 1.0, -1.0), yaw=-90.0, pitch=0.0, rpp=4,
     return fd
 
 
-def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug=True, rows=None):
+def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug=True, rows=None, profile=None):
     """Returns dict(accum, rgba8, prim_id, chain_hash, rng_state, counters).  rows=(y0, y1) renders
     only those image rows (the arrays stay full size)."""
     W, H = int(fd.window[0]), int(fd.window[1])
@@ -232,7 +244,7 @@ def render(fd, scene, first_frame, n_frames, accum=None, n_threads=0, want_debug
     chain = np.zeros((H, W), dtype=np.uint32)
     rng = np.zeros((H, W), dtype=np.uint32)
     counters = np.zeros(N_COUNTERS, dtype=np.uint64)
-    rc = lib().orc_render_rows(C.byref(fd), scene.spheres, scene.tris, scene.n_tris.value, scene.meshes,
+    rc = lib(profile).orc_render_rows(C.byref(fd), scene.spheres, scene.tris, scene.n_tris.value, scene.meshes,
                                first_frame, n_frames,
                                accum.ctypes.data, rgba8.ctypes.data,
                                prim.ctypes.data if want_debug else None,

@@ -5,10 +5,11 @@ import pytest
 import cases
 
 
+@pytest.mark.parametrize("profile", ["strict", "fma"])
 @pytest.mark.parametrize("name", sorted(cases.CASES))
-def test_oracle_matches_golden(oracle, name):
-    got = cases.run_oracle(cases.CASES[name])
-    want = cases.load_golden(name)
+def test_oracle_matches_golden(oracle, name, profile):
+    got = cases.run_oracle(cases.CASES[name], profile=profile)
+    want = cases.load_golden(name, profile)
     assert cases.bits_equal(got["accum"], want["accum"])
     for key in ("rgba8", "prim_id", "chain_hash", "rng_state"):
         assert np.array_equal(got[key], want[key]), key
@@ -20,3 +21,16 @@ def test_oracle_thread_count_does_not_change_results(oracle):
     a = cases.run_oracle(case, n_threads=1)
     b = cases.run_oracle(case, n_threads=5)
     assert cases.bits_equal(a["accum"], b["accum"]) and a["counters"] == b["counters"]
+
+
+def test_profiles_differ_by_rounding_only(oracle):
+    """The fused profile is a different rounding of the same computation: same RNG streams where the hit
+    sequences agree, images within a small tolerance, and not the same bits (the second library really fuses)."""
+    name = "c3_mesh_bench_pose"
+    a, b = cases.load_golden(name, "strict"), cases.load_golden(name, "fma")
+    assert not cases.bits_equal(a["accum"], b["accum"])
+    same_chain = a["chain_hash"] == b["chain_hash"]
+    assert same_chain.mean() > 0.99
+    assert np.array_equal(a["rng_state"][same_chain], b["rng_state"][same_chain])
+    d = np.abs(a["accum"][same_chain].astype(np.float64) - b["accum"][same_chain].astype(np.float64))
+    assert d.max() < 1e-3 * max(1.0, float(np.abs(a["accum"]).max()))

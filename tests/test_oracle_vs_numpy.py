@@ -20,8 +20,8 @@ def _records(osc, rtmi_host):
     return sph, tri, msh
 
 
-def _pow_fn(oracle):
-    lib = oracle.lib()
+def _pow_fn(oracle, profile=None):
+    lib = oracle.lib(profile)
 
     def f(x, y):
         x = np.asarray(x, dtype=np.float32)
@@ -38,7 +38,8 @@ def _pow_fn(oracle):
     ("spheres", 1, 8, 3, 2),        # spheres only, continuing a sum
     ("reference", 3, 1, 7, 1),      # single-segment paths, odd sample count
 ])
-def test_oracle_matches_numpy_restatement(oracle, rtmi, scene, rpp, depth, first, n):
+@pytest.mark.parametrize("profile", ["strict", "fma"])
+def test_oracle_matches_numpy_restatement(oracle, rtmi, scene, rpp, depth, first, n, profile):
     w, h = 24, 14
     case = dict(scene=scene, pose=cases.BENCH_POSE, size=(w, h), rpp=rpp, max_bounce=depth)
     osc = cases.oracle_scene(case)
@@ -46,10 +47,10 @@ def test_oracle_matches_numpy_restatement(oracle, rtmi, scene, rpp, depth, first
     rs = np.random.RandomState(4)
     seed = rs.uniform(0.0, 2.0, size=(h, w, 4)).astype(np.float32)
     seed[..., 3] = 1.0
-    want = oracle.render(fd, osc, first, n, accum=seed)
+    want = oracle.render(fd, osc, first, n, accum=seed, profile=profile)
 
     sph, tri, msh = _records(osc, rtmi.host)
-    sh = np_shader.Shader(fd, sph, tri, msh, _pow_fn(oracle))
+    sh = np_shader.Shader(fd, sph, tri, msh, _pow_fn(oracle, profile), fused=profile == "fma")
     accum = seed.copy()
     with np.errstate(all="ignore"):
         for f in range(first, first + n):
