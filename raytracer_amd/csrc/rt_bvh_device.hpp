@@ -159,13 +159,13 @@ __device__ __forceinline__ bool bvh_at_inner(const BvhWalk &w)
 // first slot; consecutive levels are stride words apart.
 //
 // A node is 32 bytes: two child references and twelve 16-bit plane positions q in the scene's frame,
-// plane = origin + q * step.  The float 2^23 + q is assembled in place (its bits are 0x4B000000 | q) and
-// one fused multiply-add per plane gives the plane relative to the ray origin:
-//     (2^23 + q) * step + (origin - 2^23 * step - o).
-// The upload chose q so that the quantised box encloses the child's box in exact arithmetic; what the
-// three roundings here (of origin - 2^23 step, of the subtraction of o, of the fused result) can move a
-// plane by is below 2^-24 (|origin| + 260 * 65535 step + 2 |plane - o|), which sc.bvh_slack and 2^-22 of
-// the largest distance component cover.
+// plane = origin + q * step.  A count becomes a float with one conversion that also picks its half of the
+// word (v_cvt_f32_u32 with a word select), and one fused multiply-add gives the plane relative to the ray
+// origin: q * step + (origin - o).
+// The upload chose q so that the quantised box encloses the child's box in exact arithmetic; the two
+// roundings here (of origin - o, of the fused result) move a plane by less than
+// 2^-24 (|origin - o| + |plane - o|) <= 2^-24 (2 |plane - o| + 65535 step), which 2^-22 of the largest
+// distance component and sc.bvh_slack cover.
 //
 // Both boxes are grown by ONE margin, computed for their union: D^2 over the union bounds |oc|^2 for
 // everything below either child, and the smallest radius in the hierarchy gives the largest margin.
@@ -186,9 +186,8 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
     const float t_limit = w.best.t * kBvhTSlack;
     const float cx = sc.bvh_base[0] - o.x, cy = sc.bvh_base[1] - o.y, cz = sc.bvh_base[2] - o.z;
     const float sx = sc.bvh_step[0], sy = sc.bvh_step[1], sz = sc.bvh_step[2];
-    // 2^23 + lower count, 2^23 + upper count
-    auto lower = [](uint32_t packed) { return __uint_as_float((packed & 0xFFFFu) | 0x4B000000u); };
-    auto upper = [](uint32_t packed) { return __uint_as_float(__builtin_amdgcn_alignbit(0x4B00u, packed, 16u)); };
+    auto lower = [](uint32_t packed) { return (float)(packed & 0xFFFFu); };
+    auto upper = [](uint32_t packed) { return (float)(packed >> 16); };
     const float l0x = __builtin_fmaf(lower(n0.z), sx, cx), l1x = __builtin_fmaf(upper(n0.z), sx, cx);
     const float l0y = __builtin_fmaf(lower(n0.w), sy, cy), l1y = __builtin_fmaf(upper(n0.w), sy, cy);
     const float l0z = __builtin_fmaf(lower(n1.x), sz, cz), l1z = __builtin_fmaf(upper(n1.x), sz, cz);

@@ -277,7 +277,7 @@ struct DeviceScene {
     // bounding volume hierarchy (only for scenes too large for the uniform loops; null otherwise)
     const uint4 *bvh_nodes;         // [N][2]   {left, right, l.x, l.y} {l.z, r.x, r.y, r.z}: child references and, per axis,
                                     //          lower | upper << 16 step counts of the child boxes in the frame below
-    float bvh_base[3];              // frame origin - 2^23 * step per axis (the traversal builds 2^23 + q in place)
+    float bvh_base[3];              // frame origin per axis
     float bvh_step[3];
     float bvh_slack;                // bound on the rounding of a dequantised plane relative to the ray origin
     float bvh_sphere_floor;         // smallest radius in the sphere hierarchy (shrinks the margin of its boxes)
@@ -287,6 +287,7 @@ struct DeviceScene {
     const uint32_t *bvh_tri_id;     // [L]      triangle index of each leaf-order entry
     const uint32_t *bvh_mesh_root;  // [M]      root reference of each mesh's hierarchy
     uint32_t bvh_sphere_root;       // root reference of the sphere hierarchy
+    uint32_t bvh_node_count;        // nodes in bvh_nodes (all hierarchies)
 };
 
 // Fetch of a record whose index is the same in every lane.  The scene arrays are never written by a

@@ -348,13 +348,23 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
 // 8 x 8 tiles.  p.stream_cursor is the cursor and must be zero at launch.
 // --------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 64;
+// Waves per SIMD the kernel is compiled for.  5 is what the compiler picks by itself (96 registers).  6 (80
+// registers, eight values in scratch) is 3 % faster on the 10^6 + 10^6 scene, whose walks wait for memory most
+// of the time (one more wave per SIMD hides more of that than the spills cost), and 3 % slower on a scene of
+// 10^4 primitives, whose hierarchy stays in L2 and whose walks are bound by instruction issue.  The launcher
+// takes the second build when the nodes do not fit one XCD's 4 MB L2.
 #ifndef RT_STREAM_MIN_WAVES
 #define RT_STREAM_MIN_WAVES 5
 #endif
-constexpr uint32_t kStreamWavesPerCu = RT_STREAM_MIN_WAVES > 4 ? 4u * RT_STREAM_MIN_WAVES : 16u;
+#ifndef RT_STREAM_MIN_WAVES_LARGE
+#define RT_STREAM_MIN_WAVES_LARGE 6
+#endif
+constexpr uint32_t kStreamLargeSceneNodes = (4u << 20) / 32u;
 
-template <bool VALIDATE>
-__global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(const RenderParams p)
+// RPP1: the launch has one sample per pixel and frame (the launcher checks): a finished path is a finished frame,
+// and no sample counter or partial frame sum is carried.
+template <bool VALIDATE, bool RPP1 = false, int WAVES = RT_STREAM_MIN_WAVES>
+__global__ __launch_bounds__(kStreamThreads, WAVES) void k_stream(const RenderParams p)
 {
     constexpr bool BVH = true;
     RT_BVH_STACK(kStreamThreads);
@@ -372,12 +382,15 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
     bool has_pixel = false;
     uint32_t px_x = 0u, px_y = 0u;
     const V3 origin = mk(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);  // the same for every pixel
-    V3 px_dir = mk(0.0f, 0.0f, 0.0f);
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     uint32_t hash = 0u, first_prim = kMissId, fh = 0u;
     // cursor within the pixel: frame f (0-based within the launch), sample k, bounce i
     uint32_t f = 0u, k = 0u, i = 0u, rng = 0u;
-    V3 o = origin, d = px_dir;
+    // the pixel's primary direction is kept while the register budget allows; the 6-wave build recomputes it at
+    // every path start instead (about a hundred instructions against the thousands of a walk)
+    constexpr bool kKeepDir = WAVES <= 5;
+    V3 px_dir = mk(0.0f, 0.0f, 0.0f);
+    V3 o = origin, d = mk(0.0f, 0.0f, 0.0f);
     V3 light = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f), frame_light = mk(0.0f, 0.0f, 0.0f);
     BvhWalk walk;
     bvh_idle(walk);
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                     has_pixel = true;
                     px_x = x;
                     px_y = y;
-                    px_dir = s.dir;
+                    if constexpr (kKeepDir) px_dir = s.dir;
                     sum = load_sum(p, x, y, true);
                     hash = 0u;
                     first_prim = kMissId;
@@ -478,10 +491,15 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                 path_done = true;
             }
             if (path_done) {
-                frame_light = frame_light + light;
-                k++;
-                bool more = true;
-                if (k >= p.rays_per_pixel) {
+                bool more = true, frame_done = true;
+                if constexpr (RPP1) {
+                    frame_light = mk(0.0f, 0.0f, 0.0f) + light;   // incomingLight += Trace(), once (Raytracing.comp:464-468)
+                } else {
+                    frame_light = frame_light + light;
+                    k++;
+                    frame_done = k >= p.rays_per_pixel;
+                }
+                if (frame_done) {
                     frame_light = average_samples(frame_light, p);
                     if (VALIDATE) {
                         cn.c[8]++;
@@ -502,7 +520,8 @@ __global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES) void k_stream(
                 if (more) {
                     if (VALIDATE) cn.c[9]++;
                     o = origin;
-                    d = px_dir;
+                    if constexpr (kKeepDir) d = px_dir;
+                    else d = pixel_setup_xy(p, px_x, px_y, true).dir;
                     light = mk(0.0f, 0.0f, 0.0f);
                     thr = mk(1.0f, 1.0f, 1.0f);
                     i = 0u;
@@ -958,10 +977,23 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
             if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
         }
         const uint32_t n_tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
-        const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * kStreamWavesPerCu;
+        const bool large = !validate && p.scene.bvh_node_count > kStreamLargeSceneNodes;
+        const uint32_t waves_per_simd = large ? RT_STREAM_MIN_WAVES_LARGE : RT_STREAM_MIN_WAVES;
+        const uint32_t resident = (uint32_t)(cus > 0 ? cus : 1) * 4u * waves_per_simd;
         const dim3 grid_stream(n_tiles < resident ? n_tiles : resident, 1, 1);
-        if (validate) hipLaunchKernelGGL(k_stream<true>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
-        else hipLaunchKernelGGL(k_stream<false>, grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+#ifdef RT_STREAM_NO_RPP1
+        const bool one_sample = false;
+#else
+        const bool one_sample = p.rays_per_pixel == 1u;
+#endif
+        if (validate && one_sample) hipLaunchKernelGGL((k_stream<true, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (validate) hipLaunchKernelGGL((k_stream<true, false>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (large && one_sample)
+            hipLaunchKernelGGL((k_stream<false, true, RT_STREAM_MIN_WAVES_LARGE>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (large)
+            hipLaunchKernelGGL((k_stream<false, false, RT_STREAM_MIN_WAVES_LARGE>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (one_sample) hipLaunchKernelGGL((k_stream<false, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else hipLaunchKernelGGL((k_stream<false, false>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
     } else {
         return hipErrorInvalidValue;
     }

@@ -496,12 +496,12 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->dscene.materials = reinterpret_cast<const float4 *>(base + off_mat);
     c->dscene.bvh_nodes = want_bvh ? reinterpret_cast<const uint4 *>(base + off_nodes) : nullptr;
     for (int a = 0; a < 3; a++) {
-        // origin - 2^23 step, rounded once more to binary32 (that rounding is part of bvh_slack)
-        c->dscene.bvh_base[a] = (float)((double)qframe.origin[a] - 8388608.0 * (double)qframe.step[a]);
+        c->dscene.bvh_base[a] = qframe.origin[a];
         c->dscene.bvh_step[a] = qframe.step[a];
     }
-    // 2^-24 (|origin| + 260 extent) bounds what the roundings of a dequantised plane add up to (rt_bvh_device.hpp)
-    c->dscene.bvh_slack = round_up((double)qframe.origin_max * 1.2e-7 + (double)qframe.extent_max * 3.1e-5);
+    // 2^-24 of the frame's extent: the part of a dequantised plane's rounding that does not scale with its
+    // distance from the ray origin (rt_bvh_device.hpp)
+    c->dscene.bvh_slack = round_up((double)qframe.extent_max * 6.1e-8);
     c->dscene.bvh_sphere_floor = sphere_floor;
     c->dscene.bvh_sphere_geom = want_bvh ? reinterpret_cast<const float4 *>(base + off_bsph) : nullptr;
     c->dscene.bvh_sphere_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_bsid) : nullptr;
@@ -509,6 +509,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     c->dscene.bvh_tri_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_btid) : nullptr;
     c->dscene.bvh_mesh_root = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_mroot) : nullptr;
     c->dscene.bvh_sphere_root = sphere_root;
+    c->dscene.bvh_node_count = want_bvh ? (uint32_t)qnodes.size() : 0u;
     c->bvh_active = want_bvh;
     c->fused = fused;
     c->dscene.n_spheres = nS;
