@@ -244,6 +244,15 @@ def test_full_size_stress_scene(rtmi, oracle):
     assert int((out[2]["prim_id"] != rtmi.abi.MISS_ID).sum()) > w * h // 2
     assert int((rays[1] != rtmi.abi.MISS_ID).sum()) > 500
     _assert_rays_equal(rays, oracle.closest_hit(osc, o, d), "full stress scene")
+    # two samples per pixel, uninstrumented kernels: the streaming kernel's build for large scenes with a sample loop
+    fd2 = rtmi.make_frame_data(w, h, sc, pose=pose, rays_per_pixel=2, max_bounce=16)
+    two = []
+    for variant in (0, 4):
+        with rtmi.Renderer(w, h, variant=variant) as r:
+            r.upload_scene(sc)
+            r.render_frames(fd2, 1, 2)
+            two.append(r.read_accum())
+    assert cases.bits_equal(two[0], two[1])
     big = {}
     fd = rtmi.make_frame_data(1920, 1080, sc, pose=pose, rays_per_pixel=1, max_bounce=16)
     for variant in (2, 4):
