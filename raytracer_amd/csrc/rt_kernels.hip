@@ -77,6 +77,19 @@ __device__ __forceinline__ PixelSetup pixel_setup_xy(const RenderParams &p, uint
     return s;
 }
 
+// Square tile of 8x8-pixel waves per workgroup of THREADS lanes (256: 16x16 pixels, 1024: 32x32)
+template <int THREADS>
+__device__ __forceinline__ PixelSetup pixel_setup_tile(const RenderParams &p)
+{
+    constexpr uint32_t kWavesX = THREADS == 1024 ? 4u : 2u;
+    static_assert(THREADS == 256 || THREADS == 1024, "tiles of 2x2 or 4x4 waves");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * (kWavesX * 8u) + (wave % kWavesX) * 8u + (lane & 7u);
+    const uint32_t y = blockIdx.y * (kWavesX * 8u) + (wave / kWavesX) * 8u + (lane >> 3);
+    return pixel_setup_xy(p, x, y, x < p.width && y < p.height);
+}
+
 // 16x16 pixel tile per workgroup, 8x8 per wave: the float4 rows a wave touches are whole 128-byte lines
 __device__ __forceinline__ PixelSetup pixel_setup(const RenderParams &p)
 {
@@ -644,11 +657,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_from_primary(const RenderPara
 // appended to hit_list: each wave ballots its hit lanes, the workgroup reserves the slots of all its
 // waves with a single atomic, and each hit lane takes the slot given by the count of hit lanes below it.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE, bool BVH, bool STORE = false>
-__global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p)
+// The reservations are atomics on one address and limit the kernel: without a hierarchy (whose stacks would not
+// fit the LDS otherwise) a workgroup has 1024 lanes, a quarter of the reservations.
+constexpr int kClassifyThreadsLarge = 1024;
+template <bool VALIDATE, bool BVH, bool STORE = false, int THREADS = kBlockThreads>
+__global__ __launch_bounds__(THREADS) void k_classify(const RenderParams p)
 {
-    RT_BVH_STACK(kBlockThreads);
-    const PixelSetup s = pixel_setup(p);
+    static_assert(!BVH || THREADS == kBlockThreads, "the traversal stacks are sized for 256 lanes");
+    RT_BVH_STACK(THREADS);
+    const PixelSetup s = pixel_setup_tile<THREADS>(p);
     const DeviceScene &sc = p.scene;
     const uint32_t nS = p.sphere_number, nM = p.mesh_number;
     Counters seg, none;
@@ -666,10 +683,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
         }
     }
 
-    // one reservation per workgroup: the four waves leave their counts in LDS, the first thread adds
+    // one reservation per workgroup: the waves leave their counts in LDS, the first thread adds
     // the total to the list's counter (the atomics on that one address are what limits this kernel)
     // and every wave starts where the waves before it end
-    __shared__ uint32_t wave_hits[kBlockThreads / 64];
+    __shared__ uint32_t wave_hits[THREADS / 64];
     __shared__ uint32_t block_base;
     const unsigned long long mask = __ballot(hit);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_classify(const RenderParams p
     __syncthreads();
     if (threadIdx.x == 0u) {
         uint32_t total = 0u;
-        for (uint32_t w = 0; w < kBlockThreads / 64; w++) total += wave_hits[w];
+        for (uint32_t w = 0; w < THREADS / 64; w++) total += wave_hits[w];
         block_base = total != 0u ? atomicAdd(p.hit_count, total) : 0u;
     }
     __syncthreads();
@@ -956,11 +973,18 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
         } else {
             hipError_t e = hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
+            const dim3 grid_large((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1), block_large(kClassifyThreadsLarge, 1, 1);
             if (cache == RT_CACHE_STORE) {
                 if (bvh) hipLaunchKernelGGL((k_classify<false, true, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_classify<false, false, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_classify<false, false, true, kClassifyThreadsLarge>), grid_large, block_large, 0, stream, p);
+            } else if (validate && bvh) {
+                hipLaunchKernelGGL((k_classify<true, true>), grid, block, 0, stream, p);
+            } else if (validate) {
+                hipLaunchKernelGGL((k_classify<true, false, false, kClassifyThreadsLarge>), grid_large, block_large, 0, stream, p);
+            } else if (bvh) {
+                hipLaunchKernelGGL((k_classify<false, true>), grid, block, 0, stream, p);
             } else {
-                RT_LAUNCH(k_classify, grid, block);
+                hipLaunchKernelGGL((k_classify<false, false, false, kClassifyThreadsLarge>), grid_large, block_large, 0, stream, p);
             }
             if (validate) launch_paths(std::true_type{}, std::false_type{});
             else launch_paths(std::false_type{}, std::false_type{});
