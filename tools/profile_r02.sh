@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence in one go (on the GPU box): bench lines of every workload, the default bench command under
+# The profile set in one go (on the GPU box): bench lines of every workload, the default bench command under
 # rocprofv3 --kernel-trace --stats, SQ counter passes for C2 / C3 / C5, the lane tallies and cycle stamps of
 # k_paths (needs scratch/librtmi_prof.so and scratch/librtmi_stamps.so from tools/build_variant.sh).
 # Results land in gpurun_out/r02/; copy what is to be kept into profiles/.
