@@ -373,6 +373,9 @@ RTMI_API void rtmi_frame_advance(rtmi_frame_data *fd, const rtmi_camera *cam, in
 RTMI_API int rtmi_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb);
 /* Mean radiance sum / frames as a little-endian PFM (3 x float32). */
 RTMI_API int rtmi_write_pfm(const char *path, const float *accum_rgba, uint32_t width, uint32_t height, uint32_t frames);
+/* The same mean radiance as an OpenEXR file: one part, scan lines top-down, no compression, 32-bit float
+ * channels B, G, R.  No counterpart in the reference (its only output is the swapchain). */
+RTMI_API int rtmi_write_exr(const char *path, const float *accum_rgba, uint32_t width, uint32_t height, uint32_t frames);
 
 #ifdef __cplusplus
 }

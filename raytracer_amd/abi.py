@@ -159,6 +159,7 @@ PROTOTYPES = {
     "rtmi_frame_advance": (None, [C.POINTER(FrameData), C.POINTER(Camera), C.c_int]),
     "rtmi_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "rtmi_write_pfm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rtmi_write_exr": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

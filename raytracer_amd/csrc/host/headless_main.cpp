@@ -22,7 +22,7 @@ struct Options {
     bool have_pose = false;
     float pose[5] = {0.0f, 1.0f, -1.0f, -90.0f, 0.0f};
     std::string meshes = "assets/meshes";
-    std::string ppm, pfm;
+    std::string ppm, pfm, exr;
     int variant = RTMI_VARIANT_AUTO;
     bool batch = false;
     int move_at = -1;  // frame at which the W key is held for one frame (exercises reset-on-move)
@@ -36,7 +36,7 @@ struct Options {
 void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
-              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--variant 0|1|2|3|4] [--batch]\n"
+              "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--exr FILE] [--variant 0|1|2|3|4] [--batch]\n"
               "              [--move-at FRAME] [--device N] [--fan] [--profile strict|fma]\n"
               "              [--gpus N]           static camera: frames 1..N split over GPUs 0..N-1, one RCCL sum at the end\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
@@ -121,6 +121,7 @@ int main(int argc, char **argv)
         else if (a == "--meshes" && need(1)) o.meshes = argv[++i];
         else if (a == "--ppm" && need(1)) o.ppm = argv[++i];
         else if (a == "--pfm" && need(1)) o.pfm = argv[++i];
+        else if (a == "--exr" && need(1)) o.exr = argv[++i];
         else if (a == "--variant" && need(1)) o.variant = std::atoi(argv[++i]);
         else if (a == "--batch") o.batch = true;
         else if (a == "--move-at" && need(1)) o.move_at = std::atoi(argv[++i]);
@@ -312,11 +313,15 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    if (!o.pfm.empty()) {
+    if (!o.pfm.empty() || !o.exr.empty()) {
         std::vector<float> acc(np * 4);
         if (!Check(ctx, rtmi_read_accum(ctx, acc.data(), acc.size() * sizeof(float)), "rtmi_read_accum")) return 1;
-        if (rtmi_write_pfm(o.pfm.c_str(), acc.data(), o.width, o.height, shown_frame_index) != RTMI_OK) {
+        if (!o.pfm.empty() && rtmi_write_pfm(o.pfm.c_str(), acc.data(), o.width, o.height, shown_frame_index) != RTMI_OK) {
             std::fprintf(stderr, "cannot write %s\n", o.pfm.c_str());
+            return 1;
+        }
+        if (!o.exr.empty() && rtmi_write_exr(o.exr.c_str(), acc.data(), o.width, o.height, shown_frame_index) != RTMI_OK) {
+            std::fprintf(stderr, "cannot write %s\n", o.exr.c_str());
             return 1;
         }
     }

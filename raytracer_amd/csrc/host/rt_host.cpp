@@ -364,4 +364,75 @@ bool WritePFM(const char *path, const float *accumRgba, uint32_t width, uint32_t
     return std::fclose(fp) == 0;
 }
 
+// OpenEXR, the simplest form the format allows: one part, scan lines, no compression, three 32-bit float
+// channels.  Header attributes, a table with the file offset of every scan line, then per scan line {y, byte
+// count, the line's B values, its G values, its R values} (channels in alphabetical order).  All little endian.
+bool WriteEXR(const char *path, const float *accumRgba, uint32_t width, uint32_t height, uint32_t frames)
+{
+    if (width == 0 || height == 0 || width > 0x7FFFFFFFu / 12u || height > 0x7FFFFFFFu) return false;
+    std::vector<unsigned char> head;
+    auto put = [&](const void *p, size_t n) { head.insert(head.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
+    auto put_i32 = [&](int32_t v) { put(&v, 4); };
+    auto put_f32 = [&](float v) { put(&v, 4); };
+    auto put_str = [&](const char *t) { put(t, std::strlen(t) + 1); };
+    auto attribute = [&](const char *name, const char *type, int32_t size) {
+        put_str(name);
+        put_str(type);
+        put_i32(size);
+    };
+    const unsigned char magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};   // 20000630, version 2, no flags
+    put(magic, 8);
+    attribute("channels", "chlist", 3 * 18 + 1);
+    for (const char *ch : {"B", "G", "R"}) {
+        put_str(ch);
+        put_i32(2);                      // FLOAT
+        const unsigned char linear_and_reserved[4] = {0, 0, 0, 0};
+        put(linear_and_reserved, 4);
+        put_i32(1);                      // x sampling
+        put_i32(1);                      // y sampling
+    }
+    head.push_back(0);
+    attribute("compression", "compression", 1);
+    head.push_back(0);                   // none
+    for (const char *name : {"dataWindow", "displayWindow"}) {
+        attribute(name, "box2i", 16);
+        put_i32(0);
+        put_i32(0);
+        put_i32((int32_t)width - 1);
+        put_i32((int32_t)height - 1);
+    }
+    attribute("lineOrder", "lineOrder", 1);
+    head.push_back(0);                   // increasing y
+    attribute("pixelAspectRatio", "float", 4);
+    put_f32(1.0f);
+    attribute("screenWindowCenter", "v2f", 8);
+    put_f32(0.0f);
+    put_f32(0.0f);
+    attribute("screenWindowWidth", "float", 4);
+    put_f32(1.0f);
+    head.push_back(0);                   // end of the header
+
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return false;
+    bool ok = std::fwrite(head.data(), 1, head.size(), fp) == head.size();
+    const uint64_t line_bytes = 8u + 12u * (uint64_t)width;
+    uint64_t offset = head.size() + 8u * (uint64_t)height;
+    for (uint32_t y = 0; ok && y < height; y++, offset += line_bytes) ok = std::fwrite(&offset, 8, 1, fp) == 1;
+    const float div = frames ? (float)frames : 1.0f;
+    std::vector<float> line(3 * (size_t)width);
+    for (uint32_t y = 0; ok && y < height; y++) {
+        // EXR's y grows downwards; the accumulation buffer's row 0 is the bottom of the view
+        const float *src = accumRgba + 4 * (size_t)(height - 1u - y) * width;
+        for (uint32_t x = 0; x < width; x++) {
+            line[x] = src[4 * x + 2] / div;
+            line[(size_t)width + x] = src[4 * x + 1] / div;
+            line[2 * (size_t)width + x] = src[4 * x + 0] / div;
+        }
+        const int32_t yy = (int32_t)y, n = (int32_t)(12u * width);
+        ok = std::fwrite(&yy, 4, 1, fp) == 1 && std::fwrite(&n, 4, 1, fp) == 1 &&
+             std::fwrite(line.data(), sizeof(float), line.size(), fp) == line.size();
+    }
+    return (std::fclose(fp) == 0) && ok;
+}
+
 }  // namespace rtmi

@@ -97,5 +97,6 @@ bool LoadSnapshot(const char *path, Snapshot &snap);
 
 bool WritePPM(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, bool srgb);
 bool WritePFM(const char *path, const float *accumRgba, uint32_t width, uint32_t height, uint32_t frames);
+bool WriteEXR(const char *path, const float *accumRgba, uint32_t width, uint32_t height, uint32_t frames);
 
 }  // namespace rtmi

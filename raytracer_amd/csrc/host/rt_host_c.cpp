@@ -215,4 +215,16 @@ int rtmi_write_pfm(const char *path, const float *accum_rgba, uint32_t width, ui
     return rtmi::WritePFM(path, accum_rgba, width, height, frames) ? RTMI_OK : RTMI_ERR_IO;
 }
 
+int rtmi_write_exr(const char *path, const float *accum_rgba, uint32_t width, uint32_t height, uint32_t frames)
+{
+    if (!path || !accum_rgba || !width || !height) return RTMI_ERR_INVALID_ARGUMENT;
+    try {
+        return rtmi::WriteEXR(path, accum_rgba, width, height, frames) ? RTMI_OK : RTMI_ERR_IO;
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_IO;
+    }
+}
+
 }  // extern "C"

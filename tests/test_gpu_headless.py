@@ -61,9 +61,13 @@ def test_frame_loop_and_batch_write_the_same_pictures(rtmi, tmp_path):
     srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
     want = np.floor(np.clip(srgb, 0, 1) * 255.0 + 0.5).astype(np.int32)
     assert np.abs(_read_ppm(ppm).astype(np.int32) - want).max() <= 1
-    pfm2 = tmp_path / "b.pfm"
-    _run(rtmi, "--frames", "5", "--batch", "--pose", *POSE, "--pfm", str(pfm2))
+    pfm2, exr = tmp_path / "b.pfm", tmp_path / "b.exr"
+    _run(rtmi, "--frames", "5", "--batch", "--pose", *POSE, "--pfm", str(pfm2), "--exr", str(exr))
     assert cases.bits_equal(_read_pfm(pfm2), mean)
+    # the EXR holds the same mean radiance, top row first, as planes B, G, R
+    from test_host import _read_exr
+    _, planes = _read_exr(exr.read_bytes())
+    assert cases.bits_equal(np.stack([planes["R"], planes["G"], planes["B"]], axis=-1), mean[::-1])
 
 
 def test_scene_file_script_and_snapshots(rtmi, tmp_path):

@@ -180,6 +180,71 @@ def test_ppm_and_pfm_writers(rtmi, tmp_path):
     assert lib.rtmi_write_ppm(b"/nonexistent_dir/x.ppm", img.ctypes.data, w, h, 0) == rtmi.abi.ERR_IO
 
 
+def _read_exr(raw):
+    """A reader for the plain form of OpenEXR (one part, scan lines, no compression), written from the
+    format's file layout: returns (attributes, {channel name: [h, w] float32 array, top row first})."""
+    import struct
+    assert struct.unpack_from("<i", raw, 0)[0] == 20000630
+    version = struct.unpack_from("<I", raw, 4)[0]
+    assert version & 0xFF == 2 and version >> 8 == 0          # version 2, no tiles / long names / deep data / parts
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        end = raw.index(b"\0", pos)
+        name = raw[pos:end].decode()
+        pos = end + 1
+        end = raw.index(b"\0", pos)
+        kind = raw[pos:end].decode()
+        pos = end + 1
+        size = struct.unpack_from("<i", raw, pos)[0]
+        attrs[name] = (kind, raw[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    kind, box = attrs["dataWindow"]
+    assert kind == "box2i"
+    x0, y0, x1, y1 = struct.unpack("<4i", box)
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    channels, c = [], 0
+    blob = attrs["channels"][1]
+    while blob[c] != 0:
+        end = blob.index(b"\0", c)
+        pixel_type, linear, xs, ys = struct.unpack_from("<iB3xii", blob, end + 1)
+        channels.append((blob[c:end].decode(), pixel_type, xs, ys))
+        c = end + 1 + 16
+    assert c == len(blob) - 1
+    offsets = struct.unpack_from("<%dQ" % h, raw, pos)
+    assert offsets[0] == pos + 8 * h
+    out = {name: np.zeros((h, w), dtype=np.float32) for name, _, _, _ in channels}
+    for row, off in enumerate(offsets):
+        y, nbytes = struct.unpack_from("<ii", raw, off)
+        assert y == y0 + row and nbytes == 4 * w * len(channels)
+        for k, (name, pixel_type, xs, ys) in enumerate(channels):
+            assert pixel_type == 2 and xs == 1 and ys == 1
+            out[name][row] = np.frombuffer(raw, dtype="<f4", count=w, offset=off + 8 + 4 * w * k)
+    assert offsets[-1] + 8 + 4 * w * len(channels) == len(raw)
+    return attrs, out
+
+
+def test_exr_writer(rtmi, tmp_path):
+    lib = rtmi.abi.load()
+    w, h, frames = 5, 3, 7
+    rs = np.random.RandomState(3)
+    acc = rs.uniform(0.0, 40.0, size=(h, w, 4)).astype(np.float32)
+    acc[1, 2, :3] = [np.inf, 0.0, 1e-40]
+    p = tmp_path / "a.exr"
+    assert lib.rtmi_write_exr(str(p).encode(), acc.ctypes.data, w, h, frames) == 0
+    attrs, ch = _read_exr(p.read_bytes())
+    assert sorted(ch) == ["B", "G", "R"]
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert attrs["displayWindow"] == attrs["dataWindow"]
+    assert attrs["pixelAspectRatio"][1] == np.float32(1.0).tobytes() and attrs["screenWindowWidth"][1] == np.float32(1.0).tobytes()
+    assert attrs["screenWindowCenter"] == ("v2f", bytes(8))
+    want = acc[::-1, :, :3] / np.float32(frames)                 # top row first; buffer row 0 is the bottom of the view
+    for k, name in enumerate("RGB"):
+        assert np.array_equal(ch[name].view(np.uint32), want[..., k].view(np.uint32))
+    assert lib.rtmi_write_exr(b"/nonexistent_dir/x.exr", acc.ctypes.data, w, h, frames) == rtmi.abi.ERR_IO
+    assert lib.rtmi_write_exr(str(p).encode(), None, w, h, frames) == rtmi.abi.ERR_INVALID_ARGUMENT
+
+
 def _records(sc, rtmi):
     return (bytes(sc.sphere_array())[:48 * sc.n_spheres], bytes(sc.triangles)[:96 * sc.n_triangles],
             bytes(sc.meshes)[:80 * sc.n_meshes])
