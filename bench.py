@@ -64,7 +64,10 @@ def cpu_baseline(workload, frames_hint, budget_s, profile="strict"):
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = os.cpu_count() or 1
-    cores = max(1, min(affinity, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+    # the threads this process may use: its CPU affinity, or less when the job's share of the machine is
+    # stated through OMP_NUM_THREADS (a GPU box shows every CPU of the host to each of its jobs)
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    cores = max(1, min(affinity, int(omp)) if omp.isdigit() and int(omp) > 0 else affinity)
     if scene_name == "stress":
         import raytracer_amd as R
         psc, pose = build_scene(R, scene_name)
@@ -217,6 +220,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     renderer.timing_reset(True)
+    if world > 1:
+        sr.time_collectives(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -227,10 +232,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms_total, launches = renderer.timing_read()
     renderer.timing_reset(False)
+    reduce_ms = kernel_ms_max = kernel_ms_min = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        coll_ms_total, n_coll = sr.collective_ms()
+        sr.time_collectives(False)
+        # per rank: wall seconds, render-kernel ms per step, collective ms per step (transfer + wait for slower ranks)
+        mine = torch.tensor([elapsed, kernel_ms_total / max(1, launches), coll_ms_total / max(1, n_coll)],
+                            dtype=torch.float64, device=device)
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        elapsed = float(hi[0].item())
+        kernel_ms_max, kernel_ms_min = float(hi[1].item()), float(lo[1].item())
+        # the rank that renders longest waits least: its figure is closest to the transfer itself
+        reduce_ms = {"min_over_ranks": float(lo[2].item()), "max_over_ranks": float(hi[2].item()),
+                     "rank0": float(mine[2].item()),
+                     "is": "HIP events on the rank's stream around the collective, per step: transfer + wait for slower ranks"}
 
     paths_per_step = width * height * frames * world * fd.rays_per_pixel
     value = paths_per_step * args.steps / elapsed / 1e6
@@ -303,12 +320,13 @@ def main():
         # what the counters saw reach the memory side, at this run's launch time
         result["roofline"]["hbm_gbs_from_traffic"] = traffic / (kernel_ms * 1e-3) / 1e9
     if renderer.acceleration() == R.abi.ACCEL_BVH:
-        # The hierarchy walk is a chain of dependent 64-byte gathers, bound by the memory system and not
-        # by arithmetic: price it by the bytes the walk has to fetch (two child boxes per node visit, a
-        # 20-byte record per sphere tested, a 68-byte record per triangle tested).
+        # The hierarchy walk is a chain of dependent gathers, bound by the memory system and not by
+        # arithmetic: price it by the bytes the walk has to fetch (one node record, i.e. two child boxes, per
+        # node visit, a 20-byte record per sphere tested, a 68-byte record per triangle tested).
         mesh_gates = counters["n_segments"] * fd.mesh_number
         node_visits = (counters["n_box_tests"] - mesh_gates) // 2
-        gather_bytes = node_visits * 64 + counters["n_sphere_tests"] * 20 + counters["n_tri_tests"] * 68 + algorithmic_bytes
+        node_bytes = R.abi.load().rtmi_bvh_node_bytes()   # what one visit fetches (both child boxes)
+        gather_bytes = node_visits * node_bytes + counters["n_sphere_tests"] * 20 + counters["n_tri_tests"] * 68 + algorithmic_bytes
         gather_gbs = gather_bytes / (kernel_ms * 1e-3) / 1e9
         # headline: the bytes the PMC counters saw reach the memory side (profiles/traffic_*.json, collected on
         # this configuration) over this run's launch time; the gather bytes, most of which L2 and Infinity Cache
@@ -321,11 +339,16 @@ def main():
                            "algorithmic gather bytes / kernel time (no PMC traffic file for this configuration)",
             "algorithmic_gather_bytes_per_launch": gather_bytes, "gather_gbs": gather_gbs,
             "gather_frac_of_hbm_peak": gather_gbs / HBM_PEAK_GBS, "node_visits_per_launch": node_visits,
+            "node_bytes": node_bytes,
             "fp32_tflops_algorithmic": achieved_tflops,
-            "note": "hierarchy traversal: a chain of dependent 64-byte gathers, bound by memory latency and instruction "
+            "note": "hierarchy traversal: a chain of dependent gathers (one node record per visit), bound by memory latency and instruction "
                     "issue rather than by HBM bandwidth; frac is the measured share of the HBM peak, gather_* price the "
                     "node and primitive records the walk fetches wherever they are served from",
         })
+    if world > 1:
+        result["reduce_ms"] = reduce_ms
+        result["kernel_ms_over_ranks"] = {"min": kernel_ms_min, "max": kernel_ms_max}
+        result["reduce_payload_bytes"] = width * height * 16
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, frames, args.cpu_seconds, args.profile)
     if rank == 0:

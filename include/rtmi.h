@@ -211,8 +211,15 @@ RTMI_API int rtmi_set_variant(rtmi_ctx *ctx, int variant);
 RTMI_API int rtmi_get_variant(const rtmi_ctx *ctx);
 /* Mode for the NEXT rtmi_upload_scene (default RTMI_ACCEL_AUTO); rtmi_get_acceleration tells what
  * the uploaded scene uses: RTMI_ACCEL_NONE or RTMI_ACCEL_BVH. */
+/* Bytes of one hierarchy node as the kernels fetch it (both child boxes and references): what a measurement
+ * harness prices a node visit at. */
+RTMI_API int rtmi_bvh_node_bytes(void);
 RTMI_API int rtmi_set_acceleration(rtmi_ctx *ctx, int mode);
 RTMI_API int rtmi_get_acceleration(const rtmi_ctx *ctx);
+/* GRAZING_CAP_DOC */
+#define RTMI_GRAZING_CAP_DEFAULT 0.0078125f   /* 2^-7 */
+RTMI_API int rtmi_set_grazing_cap(rtmi_ctx *ctx, float cap);
+RTMI_API float rtmi_get_grazing_cap(const rtmi_ctx *ctx);
 /* Profile for the NEXT rtmi_upload_scene (default RTMI_PROFILE_STRICT): the upload precomputes each
  * triangle's AB x AC in the profile's arithmetic, and launches use the kernels of the profile the scene
  * was uploaded under.  rtmi_get_profile tells which that is (before any upload: the mode set).  The
@@ -256,6 +263,15 @@ RTMI_API int rtmi_synchronize(rtmi_ctx *ctx);
  * display image.  RCCL is opened at run time, and only when n > 1. */
 RTMI_API int rtmi_device_count(void);
 RTMI_API int rtmi_reduce_accum(rtmi_ctx *const *contexts, uint32_t n, uint32_t root);
+/* The collective library is librccl.so unless the environment variable RTMI_RCCL_LIBRARY names another
+ * one with the same entry points (ncclCommInitAll, ncclCommDestroy, ncclReduce, ncclGroupStart, ncclGroupEnd,
+ * ncclGetErrorString).  rtmi_reduce_same_device_allowed opens it and returns 1 when it is the tests'
+ * stand-in (tests/rccl_stub), which sums images that share one GPU; RCCL proper returns 0, and
+ * rtmi_reduce_accum then wants every context on a GPU of its own.  rtmi_shutdown waits for the GPUs of the
+ * last sum, destroys the communicators rtmi_reduce_accum keeps between calls and closes the library; the
+ * next rtmi_reduce_accum opens it again.  Contexts are not touched.  No counterpart in the reference. */
+RTMI_API int rtmi_reduce_same_device_allowed(void);
+RTMI_API int rtmi_shutdown(void);
 /* Device time of the most recent render call, from HIP events recorded around its kernels on the
  * stream they ran on; waits for them to complete. */
 RTMI_API int rtmi_last_render_ms(rtmi_ctx *ctx, float *ms);

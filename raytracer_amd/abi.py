@@ -113,6 +113,9 @@ PROTOTYPES = {
     "rtmi_get_variant": (C.c_int, [_ctx]),
     "rtmi_set_acceleration": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_acceleration": (C.c_int, [_ctx]),
+    "rtmi_bvh_node_bytes": (C.c_int, []),
+    "rtmi_set_grazing_cap": (C.c_int, [_ctx, C.c_float]),
+    "rtmi_get_grazing_cap": (C.c_float, [_ctx]),
     "rtmi_set_profile": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_profile": (C.c_int, [_ctx]),
     "rtmi_clear_accum": (C.c_int, [_ctx]),
@@ -126,6 +129,8 @@ PROTOTYPES = {
     "rtmi_synchronize": (C.c_int, [_ctx]),
     "rtmi_device_count": (C.c_int, []),
     "rtmi_reduce_accum": (C.c_int, [C.POINTER(_ctx), C.c_uint32, C.c_uint32]),
+    "rtmi_reduce_same_device_allowed": (C.c_int, []),
+    "rtmi_shutdown": (C.c_int, []),
     "rtmi_last_render_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
     "rtmi_timing_reset": (C.c_int, [_ctx, C.c_int]),
     "rtmi_timing_read": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <exception>
 #include <numeric>
 #include <system_error>
@@ -351,9 +352,18 @@ void QuantizeNodes(const std::vector<BvhNode> &nodes, QFrame &frame, std::vector
                 continue;
             }
             const double o = frame.origin[a], st = frame.step[a];
-            long long ql = (long long)std::floor(((double)l[a] - o) / st) - 1;   // one step of slack each way: the
-            long long qh = (long long)std::ceil(((double)h[a] - o) / st) + 1;    // divisions above are rounded
-            if (!std::isfinite(l[a]) || !std::isfinite(h[a]) || ql < -1 || qh > 65536) bounded = false;
+            if (!std::isfinite(l[a]) || !std::isfinite(h[a])) {
+                // an infinite bound has no step count (and must not reach the integer conversion below)
+                bounded = false;
+                q[a] = 0xFFFF0000u;   // the whole frame; the child is flagged and visited whatever its box says
+                continue;
+            }
+            // one step of slack each way: the divisions are rounded.  The quotients are clamped before the
+            // conversion: a plane far outside the frame must not overflow the integer
+            const double fl = std::min(std::max(std::floor(((double)l[a] - o) / st) - 1.0, -2.0), 65537.0);
+            const double fh = std::min(std::max(std::ceil(((double)h[a] - o) / st) + 1.0, -2.0), 65537.0);
+            long long ql = (long long)fl, qh = (long long)fh;
+            if (ql < -1 || qh > 65536) bounded = false;
             ql = std::min(std::max(ql, 0ll), 65535ll);
             qh = std::min(std::max(qh, 0ll), 65535ll);
             // what was clamped must still enclose
@@ -371,6 +381,158 @@ void QuantizeNodes(const std::vector<BvhNode> &nodes, QFrame &frame, std::vector
         if (!pack(nd.l_lo, nd.l_hi, q.l)) q.left |= kUnboundedFlag;
         if (!pack(nd.r_lo, nd.r_hi, q.r)) q.right |= kUnboundedFlag;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rays almost inside a triangle's plane (see rt_bvh.hpp)
+
+namespace {
+
+constexpr double kPi2 = 1.57079632679489661923;
+// 2 (reach and the error of t) x 5.5 (rounding constant) x 1.82 (D + 0.41 longest edge <= 1.82 x the node's
+// distance bound) x 2^-24, over the usual margin of 2^-12 of the distance
+constexpr double kGrazeX = 2.0 * 5.5 * 1.82 * 5.9604644775390625e-8 * 4096.0;
+constexpr double kReachPerG = 5.9604644775390625e-8 * 1e6;   // eps * 1e6
+
+struct ConeAcc {
+    double sum[3] = {0.0, 0.0, 0.0};
+    double graze_x = 0.0, reach = 0.0;
+    uint32_t n = 0;
+    bool wild = false;
+};
+
+struct GrazeBuilder {
+    const std::vector<BvhNode> &nodes;
+    const std::vector<uint32_t> &order;
+    const std::vector<TriGraze> &tris;
+    uint32_t leaf_base;
+    std::vector<GrazeNode> &out;
+
+    // One child: the triangles at leaf positions [b, e).
+    void Child(uint32_t b, uint32_t e, uint32_t &cone, float &reach) const
+    {
+        ConeAcc acc;
+        for (uint32_t k = b; k < e; k++) {
+            const TriGraze &t = tris[order[k]];
+            if (t.wild) acc.wild = true;
+            if (!t.contributes) continue;
+            for (int a = 0; a < 3; a++) acc.sum[a] += t.unit_normal[a];
+            acc.graze_x = std::max(acc.graze_x, t.graze_x);
+            acc.reach = std::max(acc.reach, t.reach);
+            acc.n++;
+        }
+        if (acc.wild) {
+            cone = 0xFF000000u;
+            reach = INFINITY;
+            return;
+        }
+        if (acc.n == 0) {
+            // nothing below can be hit: no ray is ever in the band (T = smallest code, axis 0 would make every
+            // ray pass, so the axis is a unit vector and reach 0 keeps the usual margin even then)
+            cone = 0x0000007Fu;
+            reach = 0.0f;
+            return;
+        }
+        float r = (float)acc.reach;
+        if ((double)r < acc.reach) r = std::nextafterf(r, INFINITY);
+        reach = r;
+        const double len = std::sqrt(acc.sum[0] * acc.sum[0] + acc.sum[1] * acc.sum[1] + acc.sum[2] * acc.sum[2]);
+        if (!(len > 1e-9 * acc.n) || !(acc.graze_x < 1.0)) {
+            cone = 0xFF000000u;
+            return;
+        }
+        int q[3];
+        double ql = 0.0;
+        for (int a = 0; a < 3; a++) {
+            q[a] = (int)std::lrint(127.0 * acc.sum[a] / len);
+            ql += (double)q[a] * q[a];
+        }
+        if (ql == 0.0) {
+            cone = 0xFF000000u;
+            return;
+        }
+        // the half-angle of the cone about the axis AS STORED
+        double cos_min = 1.0;
+        for (uint32_t k = b; k < e; k++) {
+            const TriGraze &t = tris[order[k]];
+            if (!t.contributes) continue;
+            const double c = (t.unit_normal[0] * q[0] + t.unit_normal[1] * q[1] + t.unit_normal[2] * q[2]) / std::sqrt(ql);
+            cos_min = std::min(cos_min, c);
+        }
+        const double theta = std::acos(std::min(1.0, std::max(-1.0, cos_min)));
+        const double band = theta + std::asin(acc.graze_x) + 1e-6;
+        if (!(band < kPi2)) {
+            cone = 0xFF000000u;
+            return;
+        }
+        const double s = std::sin(band);
+        // the kernel compares (d . q)^2 with T dot(d, d), both in binary32: 2^-18 relative covers their rounding
+        const double need = s * s * ql * (1.0 + 1e-4) + 4e-6 * ql;
+        uint32_t code = 0;
+        while (code < 255u && (double)GrazeConeThreshold(code) < need) code++;
+        cone = (code << 24) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[1] & 0xFF) << 8) | (uint32_t)(q[0] & 0xFF);
+    }
+
+    // Returns the range of leaf positions below ref.
+    void Visit(uint32_t ref, uint32_t &b, uint32_t &e)
+    {
+        if (ref & kLeafFlag) {
+            b = (ref & kRefIndexMask) - leaf_base;
+            e = b + ((ref >> 28) & 7u);
+            return;
+        }
+        const BvhNode &nd = nodes[ref];
+        uint32_t bl, el, br, er;
+        Visit(nd.left, bl, el);
+        Visit(nd.right, br, er);
+        GrazeNode &g = out[ref];
+        Child(bl, el, g.l_cone, g.l_reach);
+        Child(br, er, g.r_cone, g.r_reach);
+        b = std::min(bl, br);
+        e = std::max(el, er);
+    }
+};
+
+}  // namespace
+
+float GrazeConeThreshold(uint32_t code)
+{
+    const uint32_t bits = (code + 992u) << 20;
+    float f;
+    static_assert(sizeof f == sizeof bits, "binary32");
+    std::memcpy(&f, &bits, sizeof f);
+    return f;
+}
+
+TriGraze TriangleGraze(const float ab[3], const float ac[3], const float n[3])
+{
+    TriGraze t;
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(ab[a]) || !std::isfinite(ac[a]) || !std::isfinite(n[a])) t.wild = true;
+    if (t.wild) return t;
+    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+    if (!(nn > 0.0)) return t;   // det = -dot(d, n) is 0 for every ray
+    const double la = std::sqrt((double)ab[0] * ab[0] + (double)ab[1] * ab[1] + (double)ab[2] * ab[2]);
+    const double lb = std::sqrt((double)ac[0] * ac[0] + (double)ac[1] * ac[1] + (double)ac[2] * ac[2]);
+    const double bc[3] = {(double)ac[0] - ab[0], (double)ac[1] - ab[1], (double)ac[2] - ab[2]};
+    const double lc = std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]);
+    const double G = std::max(2.0 * la * lb, (la + lb + lc) * std::max(la, lb));
+    for (int a = 0; a < 3; a++) t.unit_normal[a] = n[a] / nn;
+    // the rounded cross product may point up to 1.5 eps |AB||AC| / |n| away from the exact one
+    t.graze_x = std::min(1.0, kGrazeX * G / nn + 2e-7 * la * lb / nn);
+    t.reach = kReachPerG * G;
+    t.contributes = true;
+    return t;
+}
+
+void BuildGrazeNodes(const std::vector<BvhNode> &nodes, uint32_t root, uint32_t leaf_base, const std::vector<uint32_t> &order,
+                     const std::vector<TriGraze> &tris, std::vector<GrazeNode> &out)
+{
+    out.assign(nodes.size(), GrazeNode{0xFF000000u, 0xFF000000u, INFINITY, INFINITY});
+    if (root == kEmptyRef || (root & kLeafFlag)) return;
+    GrazeBuilder gb{nodes, order, tris, leaf_base, out};
+    uint32_t b, e;
+    gb.Visit(root, b, e);
 }
 
 }  // namespace rtmi

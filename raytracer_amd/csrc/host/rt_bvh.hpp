@@ -73,4 +73,50 @@ struct QFrame {
 // Chooses the frame from the finite box planes of `nodes` and converts the nodes.
 void QuantizeNodes(const std::vector<BvhNode> &nodes, QFrame &frame, std::vector<QNode> &out);
 
+// ---- Rays that run almost inside a triangle's plane (triangle hierarchies only).
+//
+// RayTriangle (Raytracing.comp:286-309) decides by the signs of three triple products (the moments of the ray
+// about the triangle's edges), each computed with an absolute error of up to c eps |edge| |ao| |d| (eps = 2^-24,
+// c <= 5.5: sqrt(2) for the cross product ao x d, 4 sin(ao, d) for the dot product and the subtraction).  Seen
+// along the ray, the triangle is a sliver of height |n| x / |edge| (n = AB x AC, x = |cos| of the angle between
+// ray and normal) whose edge lines the errors push outwards, and at a tip of the sliver two such lines meet at
+// an angle proportional to x: a ray can be accepted although it passes the triangle at a distance of up to
+//     reach(x) = c eps D G / (|n| x),   G = max(2 |AB||AC|, (|AB|+|AC|+|BC|) max(|AB|,|AC|)),  D = |ao|,
+// and the t it reports is off by less than the same amount.  det >= 1e-6 bounds x from below by
+// 1e-6 / (|d| |n|) (less the error of det itself), so reach <= about 26 g D with g = eps 1e6 G |d|, a number
+// that depends on the SIZE of the triangle: 0.0596 G |d|.
+//
+// The traversal grows boxes by 2^-12 D, which covers reach(x) for x >= graze_x = 4.91e-3 G / |n|.  For the
+// flatter rays each child of a triangle-hierarchy node carries
+//   * a cone around the normals below it, widened by asin(graze_x): a ray outside the band that the cone
+//     leaves around 90 degrees cannot be that flat to any triangle below, and takes the usual margin;
+//   * the largest g / |d| below it, from which the traversal takes the margin for rays inside the band (or
+//     visits the child whatever the box says, when g is so large that the margin would be the whole scene).
+struct TriGraze {
+    double unit_normal[3] = {0.0, 0.0, 0.0};
+    double graze_x = 0.0;    // std margin suffices for |cos(ray, normal)| >= graze_x
+    double reach = 0.0;      // g / |d|
+    bool contributes = false;  // false: the triangle can never be hit (AB x AC rounds to the zero vector)
+    bool wild = false;         // coordinates that are not finite: the child is visited whatever the ray
+};
+// ab, ac, n: the edges and their cross product as the kernels use them (rounded binary32 values).
+TriGraze TriangleGraze(const float ab[3], const float ac[3], const float n[3]);
+
+// What the kernels read per inner node of a triangle hierarchy (16 bytes, same index as the node).
+// cone word: bytes 0-2 the axis as three int8 (not normalised), byte 3 a code: 255 = every ray is in the band,
+// otherwise a ray is in the band iff (d . axis)^2 <= T dot(d, d) with T = bits((code + 992) << 20) as binary32,
+// i.e. 2^(code / 8 - 3) with a 3-bit mantissa.
+struct GrazeNode {
+    uint32_t l_cone, r_cone;
+    float l_reach, r_reach;
+};
+static_assert(sizeof(GrazeNode) == 16, "graze record is 16 bytes");
+
+// One record per node of `nodes` (a hierarchy built by BuildBvh with this leaf_base and order; tris[i] belongs
+// to box i of that call).  root is what BuildBvh returned.
+void BuildGrazeNodes(const std::vector<BvhNode> &nodes, uint32_t root, uint32_t leaf_base, const std::vector<uint32_t> &order,
+                     const std::vector<TriGraze> &tris, std::vector<GrazeNode> &out);
+// The threshold T of a cone word's code (for tests and for the builder's own rounding).
+float GrazeConeThreshold(uint32_t code);
+
 }  // namespace rtmi

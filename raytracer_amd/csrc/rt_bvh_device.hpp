@@ -174,8 +174,32 @@ __device__ __forceinline__ bool bvh_at_inner(const BvhWalk &w)
 constexpr uint32_t kBvhUnbounded = 0x08000000u;
 constexpr uint32_t kBvhIndexMask = 0x07FFFFFFu;
 
+// One child of a triangle-hierarchy node and a ray that may run almost inside the plane of a triangle below
+// it.  word: the child's cone (axis as three int8, code byte); reach: eps 1e6 G of the largest triangle below.
+// A ray outside the cone's band keeps the usual margin e.  Inside the band the rounding of RayTriangle
+// (Raytracing.comp:286-309) can accept the ray up to 26 g / (1 - 2.25 g) of the distance away from the triangle,
+// g = reach |d|: the child is given that margin, at most `cap` of the distance; from g = 0.05 on (triangles
+// whose edges are about half a unit and longer) it is visited whatever its box says.
+__device__ __forceinline__ void bvh_graze_child(uint32_t word, float reach, V3 d, float dd, float dlen, float dist, float cap, float e,
+                                                float &e_child, bool &always)
+{
+    const float ax = (float)((int)(word << 24) >> 24), ay = (float)((int)(word << 16) >> 24), az = (float)((int)(word << 8) >> 24);
+    const uint32_t code = word >> 24;
+    const float dq = __builtin_fmaf(d.z, az, __builtin_fmaf(d.y, ay, d.x * ax));
+    const float T = __uint_as_float((code + 992u) << 20);
+    // NaN compares false: such a ray counts as inside the band
+    const bool in_band = code == 255u || !(dq * dq > T * dd);
+    e_child = e;
+    always = false;
+    if (in_band) {
+        const float g = reach * dlen;
+        if (!(g < 0.05f)) always = true;
+        else e_child = __builtin_fmaf(fminf(30.0f * g, cap), dist, e);
+    }
+}
+
 template <bool COUNT>
-__device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uint32_t n_meshes, V3 o, Counters &cn, uint32_t *stack,
+__device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uint32_t n_meshes, V3 o, V3 d, Counters &cn, uint32_t *stack,
                                           uint32_t stride)
 {
     const uint4 *__restrict__ rec = sc.bvh_nodes + 2 * (size_t)(w.ref & kBvhIndexMask);
@@ -203,36 +227,49 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
     // 2^-19 of the largest distance component for the slab arithmetic, 2^-22 of it and the frame's slack for
     // the planes themselves
     const float e = __builtin_fmaf(2.1457672119140625e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r) + sc.bvh_slack;
+    // triangle hierarchies: the children's own margins for rays that may run inside a triangle's plane
+    float el = e, er = e;
+    bool always_l = false, always_r = false;
+    if (!w.is(BvhWalk::kInSpheres)) {
+        const uint4 gz = sc.bvh_graze[(w.ref & kBvhIndexMask) - sc.bvh_graze_first];
+        // upper bounds of |d| and of the distance to anything below the node (hardware square root: 1 ulp)
+        const float dlen = __builtin_amdgcn_sqrtf(w.a) * 1.000001f;
+        const float dist = __builtin_amdgcn_sqrtf(d2) * 1.000001f;
+        bvh_graze_child(gz.x, __uint_as_float(gz.z), d, w.a, dlen, dist, sc.bvh_graze_cap, e, el, always_l);
+        bvh_graze_child(gz.y, __uint_as_float(gz.w), d, w.a, dlen, dist, sc.bvh_graze_cap, e, er, always_r);
+    }
     // Entry and exit distances of the grown boxes.  NaN (0 * inf, inf - inf) makes a comparison false,
     // which keeps the box.
     const V3 inv = w.inv;
-    const float a1 = (l0x - e) * inv.x, a2 = (l1x + e) * inv.x;
-    const float a3 = (l0y - e) * inv.y, a4 = (l1y + e) * inv.y;
-    const float a5 = (l0z - e) * inv.z, a6 = (l1z + e) * inv.z;
-    const float b1 = (r0x - e) * inv.x, b2 = (r1x + e) * inv.x;
-    const float b3 = (r0y - e) * inv.y, b4 = (r1y + e) * inv.y;
-    const float b5 = (r0z - e) * inv.z, b6 = (r1z + e) * inv.z;
+    const float a1 = (l0x - el) * inv.x, a2 = (l1x + el) * inv.x;
+    const float a3 = (l0y - el) * inv.y, a4 = (l1y + el) * inv.y;
+    const float a5 = (l0z - el) * inv.z, a6 = (l1z + el) * inv.z;
+    const float b1 = (r0x - er) * inv.x, b2 = (r1x + er) * inv.x;
+    const float b3 = (r0y - er) * inv.y, b4 = (r1y + er) * inv.y;
+    const float b5 = (r0z - er) * inv.z, b6 = (r1z + er) * inv.z;
     const float tl = fmaxf(fmaxf(fminf(a1, a2), fminf(a3, a4)), fminf(a5, a6));
     const float tl_far = fminf(fminf(fmaxf(a1, a2), fmaxf(a3, a4)), fmaxf(a5, a6));
     const float tr = fmaxf(fmaxf(fminf(b1, b2), fminf(b3, b4)), fminf(b5, b6));
     const float tr_far = fminf(fminf(fmaxf(b1, b2), fmaxf(b3, b4)), fmaxf(b5, b6));
     const uint32_t L = n0.x, R = n0.y;
-    const bool hl = ((L & kBvhUnbounded) != 0u) || (!(tl_far < 0.0f) && !(tl > tl_far) && !(tl > t_limit));
-    const bool hr = ((R & kBvhUnbounded) != 0u) || (!(tr_far < 0.0f) && !(tr > tr_far) && !(tr > t_limit));
-    if (hl && hr) {
-        const bool right_first = tr < tl;
+    const bool hl = ((L & kBvhUnbounded) != 0u) || always_l || (!(tl_far < 0.0f) && !(tl > tl_far) && !(tl > t_limit));
+    const bool hr = ((R & kBvhUnbounded) != 0u) || always_r || (!(tr_far < 0.0f) && !(tr > tr_far) && !(tr > t_limit));
+    // Where the walk goes next.  Written with selects on purpose: as a chain of if / else if / else (which
+    // is how this read before) hipcc 7.2 has been seen to drop the copy that carries the popped or the right
+    // child's reference into the register of w.ref in one instantiation, leaving lanes on a stale reference.
+    const bool both = hl && hr, any = hl || hr;
+    const bool right_first = tr < tl;
+    if (both) {
         stack[(uint32_t)w.sp * stride] = right_first ? L : R;  // sp < kBvhStack: one entry per level
         w.sp++;
-        w.ref = right_first ? R : L;
-    } else if (hl) {
-        w.ref = L;
-    } else if (hr) {
-        w.ref = R;
-    } else if (w.sp == 0) {
-        bvh_group_done(w, n_meshes);
-    } else {
-        w.ref = stack[(uint32_t)(--w.sp) * stride];
     }
+    uint32_t next = (hr && (!hl || right_first)) ? R : L;
+    if (!any) {
+        next = w.ref;
+        if (w.sp == 0) bvh_group_done(w, n_meshes);
+        else next = stack[(uint32_t)(--w.sp) * stride];
+    }
+    w.ref = next;
 }
 
 // RaySphere (Raytracing.comp:130-161) for leaf entry e, whose record is g = {centre, r^2}
@@ -382,7 +419,7 @@ __device__ __forceinline__ void bvh_pass(bool stepping, BvhWalk &w, const Device
     const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
     const uint32_t n_other = (uint32_t)__popcll(__ballot(other));
     if (n_inner != 0u && n_other * RT_BVH_WAIT_DEN < n_inner * RT_BVH_WAIT_NUM) {
-        if (inner) bvh_inner<COUNT>(w, sc, n_meshes, o, cn, stack, stride);
+        if (inner) bvh_inner<COUNT>(w, sc, n_meshes, o, d, cn, stack, stride);
     } else {
         if (other) bvh_other<COUNT>(w, sc, n_spheres, n_meshes, o, d, cn, stack, stride);
     }

@@ -288,6 +288,11 @@ struct DeviceScene {
     const uint32_t *bvh_mesh_root;  // [M]      root reference of each mesh's hierarchy
     uint32_t bvh_sphere_root;       // root reference of the sphere hierarchy
     uint32_t bvh_node_count;        // nodes in bvh_nodes (all hierarchies)
+    // rays almost inside a triangle's plane: per node of the meshes' hierarchies {left cone, right cone,
+    // left reach, right reach} (rt_bvh_device.hpp); entry 0 belongs to node bvh_graze_first
+    const uint4 *bvh_graze;
+    uint32_t bvh_graze_first;
+    float bvh_graze_cap;            // largest margin, as a fraction of the distance, that such a ray is given
 };
 
 // Fetch of a record whose index is the same in every lane.  The scene arrays are never written by a
@@ -295,12 +300,16 @@ struct DeviceScene {
 // compiler use one scalar load (s_load_dwordx4) into SGPRs whatever other memory traffic the kernel has.
 __device__ __forceinline__ float4 ld_uniform(const float4 *base, uint32_t index)
 {
+#ifdef RT_HOST_EMULATION   // the tests' host build of this header: an ordinary load
+    return base[index];
+#else
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 v = ((const __attribute__((address_space(4))) f32x4 *)base)[index];
 #pragma clang diagnostic pop
     return make_float4(v.x, v.y, v.z, v.w);
+#endif
 }
 
 struct Hit {

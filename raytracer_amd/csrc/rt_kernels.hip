@@ -952,8 +952,12 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
         if (cache != RT_CACHE_NONE && (validate || !p.primary || !p.primary_mat)) return hipErrorInvalidValue;
         // one single-wave workgroup per 64 list entries; the list length is only known on the device,
         // so the grid covers the worst case and surplus workgroups leave at once
+        // (k_paths may deal a short list out 32 or 16 pixels to a wave: the grid allows for twice as many
+        // waves as 64 to a wave need, four times as many for images up to 2^20 pixels, where surplus
+        // workgroups cost next to nothing)
         const uint32_t n_pixels = p.width * p.height;
-        const dim3 grid_paths((n_pixels + 63u) / 64u, 1, 1);
+        const uint32_t per_group = bvh ? 64u : (n_pixels <= (1u << 20) ? 16u : 32u);
+        const dim3 grid_paths((n_pixels + per_group - 1u) / per_group, 1, 1);
         const dim3 block_paths(kPathsThreads, 1, 1);
         // k_paths for this scene: with a hierarchy, without meshes (no mesh code at all), or with meshes
         // (triangle tests shared by the lanes of a wave)

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "rt_bvh.hpp"
+#include "rt_pack.hpp"
 #include "rt_host.hpp"
 #include "rt_bvh_device.hpp"
 #include "rt_kernels.hpp"
@@ -74,6 +75,7 @@ struct rtmi_ctx {
     size_t scene_blob_bytes = 0;
     rtd::DeviceScene dscene{};
     int accel_mode = RTMI_ACCEL_AUTO;  // applied by the next rtmi_upload_scene
+    float graze_cap = RTMI_GRAZING_CAP_DEFAULT;  // rtmi_set_grazing_cap
     bool bvh_active = false;           // the uploaded scene carries hierarchies and the kernels use them
     int profile_mode = RTMI_PROFILE_STRICT;  // applied by the next rtmi_upload_scene
     bool fused = false;                // the uploaded scene was prepared for, and is rendered by, the fused profile
@@ -140,6 +142,13 @@ inline float round_up(double v)
 {
     float f = (float)v;
     return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+
+// The kernels' view of a packed scene whose bytes start at `base` (device memory for the library; the
+// tests' host emulation of the traversal binds the host copy the same way).
+void bind_scene(const rtmi::PackedScene &pk, const unsigned char *base, rtd::DeviceScene &ds)
+{
+    RTMI_BIND_PACKED_SCENE(pk, base, ds);
 }
 
 }  // namespace
@@ -242,242 +251,14 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     }
     if (int rc = use_device(c)) return rc;
 
-    const size_t off_sph = 0;
-    const size_t off_tri = align_up(off_sph + (size_t)nS * 16, 256);
-    const size_t off_shd = align_up(off_tri + (size_t)nT * 64, 256);
-    const size_t off_box = align_up(off_shd + (size_t)nT * 48, 256);
-    const size_t off_mat = align_up(off_box + (size_t)nM * 32, 256);
-    size_t total = align_up(off_mat + (size_t)(nS + nM) * 32, 256) + 256;
-
-    // Hierarchies: one over all spheres, one per mesh over that mesh's triangle range.  The boxes are
-    // the primitives' exact bounds (rounded outward); the margins that make skipping a box safe are
-    // applied by the traversal, relative to each ray.
     const bool fused = c->profile_mode == RTMI_PROFILE_FMA;
     const bool want_bvh = c->accel_mode == RTMI_ACCEL_BVH ||
                           (c->accel_mode == RTMI_ACCEL_AUTO && (uint64_t)nS + nT > kAutoBvhThreshold);
-    std::vector<rtmi::BvhNode> nodes;
-    std::vector<rtmi::QNode> qnodes;   // what is uploaded: the nodes in their 32-byte form
-    rtmi::QFrame qframe;
-    float sphere_floor = 0.0f;
-    std::vector<uint32_t> sphere_order, tri_order;  // leaf position -> primitive index
-    std::vector<uint32_t> mesh_root(nM, rtmi::kEmptyRef);
-    uint32_t sphere_root = rtmi::kEmptyRef;
-    size_t off_nodes = 0, off_bsph = 0, off_bsid = 0, off_btri = 0, off_btid = 0, off_mroot = 0;
-    if (want_bvh) {
-        uint64_t leaf_total = 0;
-        for (uint32_t m = 0; m < nM; m++) leaf_total += (uint32_t)meshes[m].num_triangles;
-        if (nS > rtmi::kMaxPrimitives || leaf_total > rtmi::kMaxPrimitives || nS >= rtmi::kUnboundedFlag || leaf_total >= rtmi::kUnboundedFlag)
-            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: more than %llu primitives in a hierarchy",
-                        (unsigned long long)rtmi::kMaxPrimitives);
-        try {
-            std::vector<rtmi::PrimBox> boxes(nS);
-            for (uint32_t i = 0; i < nS; i++) {
-                // the test uses the rounded square of the radius: 1e-6 relative covers that rounding
-                const double r = std::fabs((double)spheres[i].radius) * (1.0 + 1e-6);
-                for (int a = 0; a < 3; a++) {
-                    boxes[i].lo[a] = round_down((double)spheres[i].center[a] - r);
-                    boxes[i].hi[a] = round_up((double)spheres[i].center[a] + r);
-                }
-                boxes[i].margin_floor = (float)(std::fabs((double)spheres[i].radius) * 0.999999);
-                // the smallest radius of all (not a number counts as 0): one margin floor for the whole hierarchy
-                const float f = boxes[i].margin_floor >= 0.0f ? boxes[i].margin_floor : 0.0f;
-                sphere_floor = (i == 0u || f < sphere_floor) ? f : sphere_floor;
-            }
-            // the sphere hierarchy on a thread of its own while the meshes are built below; its nodes
-            // are the first in the node array either way
-            std::exception_ptr sphere_failed;
-            std::thread sphere_builder;
-            try {
-                sphere_builder = std::thread([&] {
-                    try {
-                        sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);
-                    } catch (...) {
-                        sphere_failed = std::current_exception();
-                    }
-                });
-            } catch (const std::system_error &) {
-                sphere_root = rtmi::BuildBvh(boxes, nodes, sphere_order, 0u);  // no thread to be had: build it here
-            }
-            struct Joiner {
-                std::thread &t;
-                ~Joiner() { if (t.joinable()) t.join(); }
-            } join_on_exit{sphere_builder};
-            // The meshes' hierarchies do not depend on each other: a few threads build them side by
-            // side, each mesh into node and order vectors of its own, which are then appended in mesh
-            // order (node references moved), so the result does not depend on the thread count.
-            std::vector<uint32_t> leaf_base(nM + 1u, 0u);
-            for (uint32_t m = 0; m < nM; m++) leaf_base[m + 1] = leaf_base[m] + (uint32_t)meshes[m].num_triangles;
-            std::vector<std::vector<rtmi::BvhNode>> mesh_nodes(nM);
-            std::vector<std::vector<uint32_t>> mesh_order(nM);
-            auto build_meshes = [&](uint32_t first, uint32_t stride) {
-                std::vector<rtmi::PrimBox> tb;
-                for (uint32_t m = first; m < nM; m += stride) {
-                    const uint32_t start = (uint32_t)meshes[m].start_triangle, count = (uint32_t)meshes[m].num_triangles;
-                    tb.resize(count);
-                    for (uint32_t k = 0; k < count; k++) {
-                        const rtmi_triangle &t = tris[start + k];
-                        for (int a = 0; a < 3; a++) {
-                            tb[k].lo[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
-                            tb[k].hi[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
-                        }
-                        tb[k].margin_floor = 0.0f;
-                    }
-                    mesh_root[m] = rtmi::BuildBvh(tb, mesh_nodes[m], mesh_order[m], leaf_base[m]);
-                    for (uint32_t k = 0; k < count; k++) mesh_order[m][k] += start;
-                }
-            };
-            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-            const uint32_t n_threads = (leaf_total < 32768u || nM < 2u) ? 1u : std::min({nM, hw, 8u});
-            if (n_threads == 1u) {
-                build_meshes(0u, 1u);
-            } else {
-                std::vector<std::thread> pool;
-                std::vector<std::exception_ptr> failed(n_threads);
-                std::vector<uint32_t> not_started;
-                for (uint32_t t = 0; t < n_threads; t++) {
-                    try {
-                        pool.emplace_back([&, t] {
-                            try {
-                                build_meshes(t, n_threads);
-                            } catch (...) {
-                                failed[t] = std::current_exception();
-                            }
-                        });
-                    } catch (const std::system_error &) {
-                        not_started.push_back(t);
-                    }
-                }
-                // shares whose thread could not be created are built here; the result is the same
-                std::exception_ptr here;
-                try {
-                    for (uint32_t t : not_started) build_meshes(t, n_threads);
-                } catch (...) {
-                    here = std::current_exception();
-                }
-                for (std::thread &t : pool) t.join();
-                if (here) std::rethrow_exception(here);
-                for (const std::exception_ptr &f : failed)
-                    if (f) std::rethrow_exception(f);
-            }
-            if (sphere_builder.joinable()) sphere_builder.join();
-            if (sphere_failed) std::rethrow_exception(sphere_failed);
-            tri_order.reserve(leaf_total);
-            for (uint32_t m = 0; m < nM; m++) {
-                const uint32_t shift = (uint32_t)nodes.size();
-                for (rtmi::BvhNode &nd : mesh_nodes[m]) {
-                    if (!(nd.left & rtmi::kLeafFlag)) nd.left += shift;
-                    if (!(nd.right & rtmi::kLeafFlag)) nd.right += shift;
-                }
-                if (!(mesh_root[m] & rtmi::kLeafFlag)) mesh_root[m] += shift;  // kEmptyRef has the flag set
-                nodes.insert(nodes.end(), mesh_nodes[m].begin(), mesh_nodes[m].end());
-                tri_order.insert(tri_order.end(), mesh_order[m].begin(), mesh_order[m].end());
-                std::vector<rtmi::BvhNode>().swap(mesh_nodes[m]);
-                std::vector<uint32_t>().swap(mesh_order[m]);
-            }
-            if (nodes.size() >= rtmi::kUnboundedFlag)
-                return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: %zu hierarchy nodes exceed the reference format", nodes.size());
-            rtmi::QuantizeNodes(nodes, qframe, qnodes);
-            std::vector<rtmi::BvhNode>().swap(nodes);
-        } catch (const std::bad_alloc &) {
-            return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation failed while building hierarchies");
-        } catch (const std::exception &ex) {
-            // e.g. std::system_error from thread creation
-            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: building hierarchies failed: %s", ex.what());
-        } catch (...) {
-            return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_upload_scene: building hierarchies failed");
-        }
-        off_nodes = align_up(total, 256);
-        off_bsph = align_up(off_nodes + qnodes.size() * sizeof(rtmi::QNode), 256);
-        off_bsid = align_up(off_bsph + (size_t)nS * 16, 256);
-        off_btri = align_up(off_bsid + (size_t)nS * 4, 256);
-        off_btid = align_up(off_btri + tri_order.size() * 64, 256);
-        off_mroot = align_up(off_btid + tri_order.size() * 4, 256);
-        total = align_up(off_mroot + (size_t)nM * 4, 256) + 256;
-    }
-    std::vector<unsigned char> blob;
-    try {
-        blob.assign(total, 0);
-    } catch (const std::bad_alloc &) {
-        return fail(c, RTMI_ERR_OUT_OF_MEMORY, "rtmi_upload_scene: host allocation of %zu bytes failed", total);
-    }
-    float *sph = reinterpret_cast<float *>(blob.data() + off_sph);
-    float *tri = reinterpret_cast<float *>(blob.data() + off_tri);
-    float *shd = reinterpret_cast<float *>(blob.data() + off_shd);
-    float *box = reinterpret_cast<float *>(blob.data() + off_box);
-    float *mat = reinterpret_cast<float *>(blob.data() + off_mat);
-
-    auto put_material = [&](uint32_t row, const rtmi_material &m) {
-        float *d = mat + 8 * (size_t)row;
-        d[0] = m.color[0]; d[1] = m.color[1]; d[2] = m.color[2]; d[3] = m.light;
-        d[4] = m.smoothness;
-    };
-    for (uint32_t i = 0; i < nS; i++) {
-        const rtmi_sphere &s = spheres[i];
-        float *d = sph + 4 * (size_t)i;
-        d[0] = s.center[0]; d[1] = s.center[1]; d[2] = s.center[2];
-        d[3] = s.radius * s.radius;
-        put_material(i, s.material);
-    }
-    for (uint32_t j = 0; j < nT; j++) {
-        const rtmi_triangle &t = tris[j];
-        float ab[3], ac[3], n[3];
-        for (int a = 0; a < 3; a++) {
-            ab[a] = t.p2[a] - t.p1[a];
-            ac[a] = t.p3[a] - t.p1[a];
-        }
-        if (fused) {
-            // the fused profile's cross product: one product rounded, the other fused into the difference
-            n[0] = std::fmaf(ab[1], ac[2], -(ac[1] * ab[2]));
-            n[1] = std::fmaf(ab[2], ac[0], -(ac[2] * ab[0]));
-            n[2] = std::fmaf(ab[0], ac[1], -(ac[0] * ab[1]));
-        } else {
-            n[0] = ab[1] * ac[2] - ac[1] * ab[2];
-            n[1] = ab[2] * ac[0] - ac[2] * ab[0];
-            n[2] = ab[0] * ac[1] - ac[0] * ab[1];
-        }
-        float *d = tri + 16 * (size_t)j;
-        for (int a = 0; a < 3; a++) {
-            d[0 + a] = t.p1[a];
-            d[4 + a] = ab[a];
-            d[8 + a] = ac[a];
-            d[12 + a] = n[a];
-        }
-        float *s = shd + 12 * (size_t)j;
-        for (int a = 0; a < 3; a++) {
-            s[0 + a] = t.n1[a];
-            s[4 + a] = t.n2[a];
-            s[8 + a] = t.n3[a];
-        }
-    }
-    for (uint32_t m = 0; m < nM; m++) {
-        const rtmi_mesh &ms = meshes[m];
-        float *d = box + 8 * (size_t)m;
-        const uint32_t start = (uint32_t)ms.start_triangle, count = (uint32_t)ms.num_triangles;
-        for (int a = 0; a < 3; a++) {
-            d[0 + a] = ms.bounding_point1[a];
-            d[4 + a] = ms.bounding_point2[a];
-        }
-        memcpy(&d[3], &start, 4);
-        memcpy(&d[7], &count, 4);
-        put_material(nS + m, ms.material);
-    }
-
-    if (want_bvh) {
-        if (!qnodes.empty()) memcpy(blob.data() + off_nodes, qnodes.data(), qnodes.size() * sizeof(rtmi::QNode));
-        float *bs = reinterpret_cast<float *>(blob.data() + off_bsph);
-        uint32_t *bi = reinterpret_cast<uint32_t *>(blob.data() + off_bsid);
-        for (uint32_t k = 0; k < nS; k++) {
-            memcpy(bs + 4 * (size_t)k, sph + 4 * (size_t)sphere_order[k], 16);
-            bi[k] = sphere_order[k];
-        }
-        float *bt = reinterpret_cast<float *>(blob.data() + off_btri);
-        uint32_t *bj = reinterpret_cast<uint32_t *>(blob.data() + off_btid);
-        for (size_t k = 0; k < tri_order.size(); k++) {
-            memcpy(bt + 16 * k, tri + 16 * (size_t)tri_order[k], 64);
-            bj[k] = tri_order[k];
-        }
-        if (nM) memcpy(blob.data() + off_mroot, mesh_root.data(), (size_t)nM * 4);
-    }
+    // everything up to the bytes that go to the device is host work (host/rt_pack.cpp)
+    rtmi::PackedScene pk;
+    std::string why;
+    if (const int rc = rtmi::PackScene(spheres, nS, tris, nT, meshes, nM, want_bvh, fused, pk, why)) return fail(c, rc, "%s", why.c_str());
+    const size_t total = pk.blob.size();
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->scene_blob_bytes < total) {
@@ -487,29 +268,10 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
         HIP_TRY(c, hipMalloc(&c->scene_blob, total));
         c->scene_blob_bytes = total;
     }
-    HIP_TRY(c, hipMemcpy(c->scene_blob, blob.data(), total, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->scene_blob, pk.blob.data(), total, hipMemcpyHostToDevice));
     unsigned char *base = static_cast<unsigned char *>(c->scene_blob);
-    c->dscene.sphere_geom = reinterpret_cast<const float4 *>(base + off_sph);
-    c->dscene.tri_isect = reinterpret_cast<const float4 *>(base + off_tri);
-    c->dscene.tri_shade = reinterpret_cast<const float4 *>(base + off_shd);
-    c->dscene.mesh_box = reinterpret_cast<const float4 *>(base + off_box);
-    c->dscene.materials = reinterpret_cast<const float4 *>(base + off_mat);
-    c->dscene.bvh_nodes = want_bvh ? reinterpret_cast<const uint4 *>(base + off_nodes) : nullptr;
-    for (int a = 0; a < 3; a++) {
-        c->dscene.bvh_base[a] = qframe.origin[a];
-        c->dscene.bvh_step[a] = qframe.step[a];
-    }
-    // 2^-24 of the frame's extent: the part of a dequantised plane's rounding that does not scale with its
-    // distance from the ray origin (rt_bvh_device.hpp)
-    c->dscene.bvh_slack = round_up((double)qframe.extent_max * 6.1e-8);
-    c->dscene.bvh_sphere_floor = sphere_floor;
-    c->dscene.bvh_sphere_geom = want_bvh ? reinterpret_cast<const float4 *>(base + off_bsph) : nullptr;
-    c->dscene.bvh_sphere_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_bsid) : nullptr;
-    c->dscene.bvh_tri_isect = want_bvh ? reinterpret_cast<const float4 *>(base + off_btri) : nullptr;
-    c->dscene.bvh_tri_id = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_btid) : nullptr;
-    c->dscene.bvh_mesh_root = want_bvh ? reinterpret_cast<const uint32_t *>(base + off_mroot) : nullptr;
-    c->dscene.bvh_sphere_root = sphere_root;
-    c->dscene.bvh_node_count = want_bvh ? (uint32_t)qnodes.size() : 0u;
+    bind_scene(pk, base, c->dscene);
+    c->dscene.bvh_graze_cap = c->graze_cap;
     c->bvh_active = want_bvh;
     c->fused = fused;
     c->dscene.n_spheres = nS;
@@ -726,6 +488,17 @@ int rtmi_set_acceleration(rtmi_ctx *c, int mode)
     c->accel_mode = mode;
     return RTMI_OK;
 }
+
+int rtmi_set_grazing_cap(rtmi_ctx *c, float cap)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!(cap >= 0.0f)) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_set_grazing_cap: %g is not a fraction of the distance", (double)cap);
+    c->graze_cap = cap;
+    c->dscene.bvh_graze_cap = cap;   // a kernel argument: the next launch reads it
+    return RTMI_OK;
+}
+
+float rtmi_get_grazing_cap(const rtmi_ctx *c) { return c ? c->graze_cap : -1.0f; }
 
 int rtmi_get_acceleration(const rtmi_ctx *c) { return c ? (c->bvh_active ? RTMI_ACCEL_BVH : RTMI_ACCEL_NONE) : RTMI_ERR_INVALID_ARGUMENT; }
 
@@ -951,6 +724,8 @@ int rtmi_reset_counters(rtmi_ctx *c)
     return RTMI_OK;
 }
 
+int rtmi_bvh_node_bytes(void) { return (int)sizeof(rtmi::QNode); }
+
 int rtmi_device_count(void)
 {
     int count = 0;
@@ -959,10 +734,14 @@ int rtmi_device_count(void)
     return count;
 }
 
-// RCCL, opened when first needed (a process that renders on one GPU never loads it).
+// RCCL, opened when first needed (a process that renders on one GPU never loads it).  The environment
+// variable RTMI_RCCL_LIBRARY names another library with the same six entry points; one that also exports
+// the marker rtmi_rccl_stub_same_device (the sum-by-copy stand-in that the tests build, which needs no second
+// GPU) lifts the rule that every context of a sum sits on a GPU of its own.
 namespace {
 struct Rccl {
     void *handle = nullptr;
+    bool same_device_ok = false;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
@@ -976,12 +755,18 @@ struct Rccl {
     bool Load(std::string &why)
     {
         if (handle) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
+        const char *named = getenv("RTMI_RCCL_LIBRARY");
+        if (named && *named) {
+            handle = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (handle) break;
+            }
         }
         if (!handle) {
-            why = dlerror();
+            const char *msg = dlerror();
+            why = msg ? msg : "dlopen failed";
             return false;
         }
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));
@@ -991,15 +776,54 @@ struct Rccl {
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
         if (!CommInitAll || !CommDestroy || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) {
-            why = "librccl lacks an expected symbol";
+            why = "the collective library lacks an expected symbol";
             dlclose(handle);
             handle = nullptr;
             return false;
         }
+        same_device_ok = dlsym(handle, "rtmi_rccl_stub_same_device") != nullptr;
         return true;
     }
+    // Communicators may still have collectives in flight on the streams they were used with: every device
+    // of the list is drained first.
+    void DropComms()
+    {
+        for (int dev : devices)
+            if (hipSetDevice(dev) == hipSuccess) (void)hipDeviceSynchronize();
+        for (ncclComm_t cm : comms)
+            if (cm) (void)CommDestroy(cm);
+        comms.clear();
+        devices.clear();
+    }
 } g_rccl;
+
+// puts the calling thread's current device back when the scope ends
+struct DeviceRestore {
+    int saved = -1;
+    DeviceRestore() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceRestore() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
 }  // namespace
+
+int rtmi_reduce_same_device_allowed(void)
+{
+    std::lock_guard<std::mutex> guard(g_rccl.lock);
+    std::string why;
+    if (!g_rccl.Load(why)) return 0;
+    return g_rccl.same_device_ok ? 1 : 0;
+}
+
+int rtmi_shutdown(void)
+{
+    std::lock_guard<std::mutex> guard(g_rccl.lock);
+    if (!g_rccl.handle) return RTMI_OK;
+    DeviceRestore restore;
+    g_rccl.DropComms();
+    dlclose(g_rccl.handle);
+    g_rccl.handle = nullptr;
+    g_rccl.same_device_ok = false;
+    return RTMI_OK;
+}
 
 // Sum of the accumulation images of n contexts, one per GPU, onto contexts[root]: one RCCL reduce over xGMI,
 // enqueued on every context's stream (no host synchronisation; the root's stream holds the sum once its
@@ -1012,24 +836,32 @@ int rtmi_reduce_accum(rtmi_ctx *const *contexts, uint32_t n, uint32_t root)
     rtmi_ctx *r = contexts[root];
     if (!r) return RTMI_ERR_INVALID_ARGUMENT;
     std::vector<int> devices(n);
+    bool shared_gpu = false;
     for (uint32_t i = 0; i < n; i++) {
         if (!contexts[i]) return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: context %u is NULL", i);
         if (contexts[i]->width != r->width || contexts[i]->height != r->height)
             return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: context %u is %ux%u, the root %ux%u", i, contexts[i]->width,
                         contexts[i]->height, r->width, r->height);
         devices[i] = contexts[i]->device;
-        for (uint32_t j = 0; j < i; j++)
-            if (devices[j] == devices[i])
-                return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: contexts %u and %u are on the same GPU (%d)", j, i, devices[i]);
+        for (uint32_t j = 0; j < i; j++) {
+            if (contexts[j] == contexts[i])
+                return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: contexts %u and %u are the same context", j, i);
+            if (devices[j] == devices[i]) shared_gpu = true;
+        }
     }
     if (n == 1) return RTMI_OK;   // a sum over one image
     std::lock_guard<std::mutex> guard(g_rccl.lock);
     std::string why;
-    if (!g_rccl.Load(why)) return fail(r, RTMI_ERR_UNSUPPORTED, "rtmi_reduce_accum: cannot open RCCL: %s", why.c_str());
+    if (!shared_gpu || (getenv("RTMI_RCCL_LIBRARY") && *getenv("RTMI_RCCL_LIBRARY"))) {
+        if (!g_rccl.Load(why)) return fail(r, RTMI_ERR_UNSUPPORTED, "rtmi_reduce_accum: cannot open RCCL: %s", why.c_str());
+    }
+    // RCCL proper wants one GPU per rank; only the tests' stand-in sums images that share one
+    if (shared_gpu && !(g_rccl.handle && g_rccl.same_device_ok))
+        return fail(r, RTMI_ERR_INVALID_ARGUMENT, "rtmi_reduce_accum: two of the contexts are on the same GPU");
+    DeviceRestore restore;
     if (g_rccl.devices != devices) {
-        for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
+        g_rccl.DropComms();
         g_rccl.comms.assign(n, nullptr);
-        g_rccl.devices.clear();
         const ncclResult_t rc = g_rccl.CommInitAll(g_rccl.comms.data(), (int)n, devices.data());
         if (rc != ncclSuccess) {
             g_rccl.comms.clear();
@@ -1039,10 +871,12 @@ int rtmi_reduce_accum(rtmi_ctx *const *contexts, uint32_t n, uint32_t root)
     }
     const size_t count = n_pixels(r) * 4;
     ncclResult_t rc = g_rccl.GroupStart();
+    if (rc != ncclSuccess) return fail(r, RTMI_ERR_HIP, "rtmi_reduce_accum: ncclGroupStart: %s", g_rccl.GetErrorString(rc));
     for (uint32_t i = 0; i < n && rc == ncclSuccess; i++) {
         if (hipSetDevice(devices[i]) != hipSuccess) rc = ncclUnhandledCudaError;
         else rc = g_rccl.Reduce(contexts[i]->accum, contexts[i]->accum, count, ncclFloat32, ncclSum, (int)root, g_rccl.comms[i], contexts[i]->stream);
     }
+    // the group is closed even after a failed call, or the library stays in group mode
     const ncclResult_t rc_end = g_rccl.GroupEnd();
     if (rc == ncclSuccess) rc = rc_end;
     if (rc != ncclSuccess) return fail(r, RTMI_ERR_HIP, "rtmi_reduce_accum: %s", g_rccl.GetErrorString(rc));

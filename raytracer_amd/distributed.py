@@ -22,7 +22,7 @@ def split_frames(total_frames, world_size, rank, first_frame=1):
     return start, n
 
 
-def render_sharded(render_range, accum, total_frames, first_frame=1, group=None, dst=None):
+def render_sharded(render_range, accum, total_frames, first_frame=1, group=None, dst=None, around_collective=None):
     """Render this rank's share of frames first_frame .. first_frame+total_frames-1 into `accum`
     (a [H, W, 4] float32 tensor the renderer is bound to) and sum the images over all ranks.
 
@@ -30,7 +30,8 @@ def render_sharded(render_range, accum, total_frames, first_frame=1, group=None,
     first == 1, exactly as rtmi_render_frames does.  With dst=None every rank ends up with the sum
     (all-reduce); otherwise only rank dst does (reduce).  Returns (first, n) of this rank.  The
     alpha channel of the sum equals the number of ranks that rendered something; the caller puts
-    it back to 1 (rtmi_resolve_output does)."""
+    it back to 1 (rtmi_resolve_output does).  around_collective, if given, is called with "before" and
+    "after" on either side of the collective (the bench records events there)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     first, n = split_frames(total_frames, world, rank, first_frame)
@@ -41,10 +42,14 @@ def render_sharded(render_range, accum, total_frames, first_frame=1, group=None,
     if n > 0:
         render_range(first, n)
     if world > 1:
+        if around_collective is not None:
+            around_collective("before")
         if dst is None:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
         else:
             dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if around_collective is not None:
+            around_collective("after")
     return first, n
 
 
@@ -69,14 +74,42 @@ class ShardedRenderer:
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         renderer.bind_accum(self.accum.data_ptr())
         renderer.set_stream(self.stream.cuda_stream)
+        self._collective_events = None   # time_collectives(True): one (before, after) event pair per render()
+
+    def time_collectives(self, enable=True):
+        """Record an event pair on this object's stream around every collective from now on (the events
+        cost no synchronisation); collective_ms() reads them."""
+        self._collective_events = [] if enable else None
+
+    def collective_ms(self):
+        """(summed milliseconds, count) between the event pairs recorded since time_collectives(True): on this
+        rank, the time from the end of its own render kernels to the completion of the collective, i.e. the
+        transfer plus the wait for slower ranks.  Waits for the events."""
+        pairs = self._collective_events or []
+        total = 0.0
+        for before, after in pairs:
+            after.synchronize()
+            total += before.elapsed_time(after)
+        n = len(pairs)
+        if self._collective_events is not None:
+            self._collective_events = []
+        return total, n
 
     def render(self, fd, total_frames, first_frame=1, group=None, dst=None):
         """This rank's share of the frames + the sum over ranks (all ranks, or rank dst only)."""
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
+        hook = None
+        if self._collective_events is not None:
+            pair = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+            def hook(which):
+                pair[0 if which == "before" else 1].record(self.stream)
+                if which == "after":
+                    self._collective_events.append(tuple(pair))
         with torch.cuda.stream(self.stream):
             rng = render_sharded(lambda first, n: self.renderer.render_frames(fd, first, n), self.accum,
-                                 total_frames, first_frame, group, dst)
+                                 total_frames, first_frame, group, dst, hook)
         caller.wait_stream(self.stream)
         return rng
 

@@ -262,6 +262,14 @@ class Renderer:
         """abi.ACCEL_AUTO / ACCEL_NONE / ACCEL_BVH for the next upload_scene."""
         self._check(self._lib.rtmi_set_acceleration(self._ctx, mode))
 
+    def set_grazing_cap(self, cap):
+        """Largest margin (fraction of the distance) the hierarchy gives rays that run almost inside a
+        triangle's plane (rtmi_set_grazing_cap); 1.0 = the proven bound, whatever it costs."""
+        self._check(self._lib.rtmi_set_grazing_cap(self._ctx, float(cap)))
+
+    def grazing_cap(self):
+        return float(self._lib.rtmi_get_grazing_cap(self._ctx))
+
     def acceleration(self):
         """What the uploaded scene uses: abi.ACCEL_NONE or abi.ACCEL_BVH."""
         return self._check(self._lib.rtmi_get_acceleration(self._ctx))
