@@ -401,6 +401,72 @@ struct ConeAcc {
     bool wild = false;
 };
 
+// Cone and reach of a set of triangles: tri(k), k in [b, e).
+template <class TriAt>
+void GrazeOfSet(uint32_t b, uint32_t e, TriAt tri, uint32_t &cone, float &reach)
+{
+    ConeAcc acc;
+    for (uint32_t k = b; k < e; k++) {
+        const TriGraze &t = tri(k);
+        if (t.wild) acc.wild = true;
+        if (!t.contributes) continue;
+        for (int a = 0; a < 3; a++) acc.sum[a] += t.unit_normal[a];
+        acc.graze_x = std::max(acc.graze_x, t.graze_x);
+        acc.reach = std::max(acc.reach, t.reach);
+        acc.n++;
+    }
+    if (acc.wild) {
+        cone = 0xFF000000u;
+        reach = INFINITY;
+        return;
+    }
+    if (acc.n == 0) {
+        // nothing below can be hit: no ray is ever in the band (T = smallest code, axis 0 would make every
+        // ray pass, so the axis is a unit vector and reach 0 keeps the usual margin even then)
+        cone = 0x0000007Fu;
+        reach = 0.0f;
+        return;
+    }
+    float r = (float)acc.reach;
+    if ((double)r < acc.reach) r = std::nextafterf(r, INFINITY);
+    reach = r;
+    const double len = std::sqrt(acc.sum[0] * acc.sum[0] + acc.sum[1] * acc.sum[1] + acc.sum[2] * acc.sum[2]);
+    if (!(len > 1e-9 * acc.n) || !(acc.graze_x < 1.0)) {
+        cone = 0xFF000000u;
+        return;
+    }
+    int q[3];
+    double ql = 0.0;
+    for (int a = 0; a < 3; a++) {
+        q[a] = (int)std::lrint(127.0 * acc.sum[a] / len);
+        ql += (double)q[a] * q[a];
+    }
+    if (ql == 0.0) {
+        cone = 0xFF000000u;
+        return;
+    }
+    // the half-angle of the cone about the axis AS STORED
+    double cos_min = 1.0;
+    for (uint32_t k = b; k < e; k++) {
+        const TriGraze &t = tri(k);
+        if (!t.contributes) continue;
+        const double c = (t.unit_normal[0] * q[0] + t.unit_normal[1] * q[1] + t.unit_normal[2] * q[2]) / std::sqrt(ql);
+        cos_min = std::min(cos_min, c);
+    }
+    const double theta = std::acos(std::min(1.0, std::max(-1.0, cos_min)));
+    const double band = theta + std::asin(acc.graze_x) + 1e-6;
+    if (!(band < kPi2)) {
+        cone = 0xFF000000u;
+        return;
+    }
+    const double s = std::sin(band);
+    // the kernel compares (d . q)^2 with T dot(d, d), both in binary32: 2^-18 relative covers their rounding
+    const double need = s * s * ql * (1.0 + 1e-4) + 4e-6 * ql;
+    uint32_t code = 0;
+    while (code < 255u && (double)GrazeConeThreshold(code) < need) code++;
+    cone = (code << 24) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[1] & 0xFF) << 8) | (uint32_t)(q[0] & 0xFF);
+}
+
 struct GrazeBuilder {
     const std::vector<BvhNode> &nodes;
     const std::vector<uint32_t> &order;
@@ -411,66 +477,7 @@ struct GrazeBuilder {
     // One child: the triangles at leaf positions [b, e).
     void Child(uint32_t b, uint32_t e, uint32_t &cone, float &reach) const
     {
-        ConeAcc acc;
-        for (uint32_t k = b; k < e; k++) {
-            const TriGraze &t = tris[order[k]];
-            if (t.wild) acc.wild = true;
-            if (!t.contributes) continue;
-            for (int a = 0; a < 3; a++) acc.sum[a] += t.unit_normal[a];
-            acc.graze_x = std::max(acc.graze_x, t.graze_x);
-            acc.reach = std::max(acc.reach, t.reach);
-            acc.n++;
-        }
-        if (acc.wild) {
-            cone = 0xFF000000u;
-            reach = INFINITY;
-            return;
-        }
-        if (acc.n == 0) {
-            // nothing below can be hit: no ray is ever in the band (T = smallest code, axis 0 would make every
-            // ray pass, so the axis is a unit vector and reach 0 keeps the usual margin even then)
-            cone = 0x0000007Fu;
-            reach = 0.0f;
-            return;
-        }
-        float r = (float)acc.reach;
-        if ((double)r < acc.reach) r = std::nextafterf(r, INFINITY);
-        reach = r;
-        const double len = std::sqrt(acc.sum[0] * acc.sum[0] + acc.sum[1] * acc.sum[1] + acc.sum[2] * acc.sum[2]);
-        if (!(len > 1e-9 * acc.n) || !(acc.graze_x < 1.0)) {
-            cone = 0xFF000000u;
-            return;
-        }
-        int q[3];
-        double ql = 0.0;
-        for (int a = 0; a < 3; a++) {
-            q[a] = (int)std::lrint(127.0 * acc.sum[a] / len);
-            ql += (double)q[a] * q[a];
-        }
-        if (ql == 0.0) {
-            cone = 0xFF000000u;
-            return;
-        }
-        // the half-angle of the cone about the axis AS STORED
-        double cos_min = 1.0;
-        for (uint32_t k = b; k < e; k++) {
-            const TriGraze &t = tris[order[k]];
-            if (!t.contributes) continue;
-            const double c = (t.unit_normal[0] * q[0] + t.unit_normal[1] * q[1] + t.unit_normal[2] * q[2]) / std::sqrt(ql);
-            cos_min = std::min(cos_min, c);
-        }
-        const double theta = std::acos(std::min(1.0, std::max(-1.0, cos_min)));
-        const double band = theta + std::asin(acc.graze_x) + 1e-6;
-        if (!(band < kPi2)) {
-            cone = 0xFF000000u;
-            return;
-        }
-        const double s = std::sin(band);
-        // the kernel compares (d . q)^2 with T dot(d, d), both in binary32: 2^-18 relative covers their rounding
-        const double need = s * s * ql * (1.0 + 1e-4) + 4e-6 * ql;
-        uint32_t code = 0;
-        while (code < 255u && (double)GrazeConeThreshold(code) < need) code++;
-        cone = (code << 24) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[1] & 0xFF) << 8) | (uint32_t)(q[0] & 0xFF);
+        GrazeOfSet(b, e, [this](uint32_t k) -> const TriGraze & { return tris[order[k]]; }, cone, reach);
     }
 
     // Returns the range of leaf positions below ref.
@@ -523,6 +530,13 @@ TriGraze TriangleGraze(const float ab[3], const float ac[3], const float n[3])
     t.reach = kReachPerG * G;
     t.contributes = true;
     return t;
+}
+
+MeshGraze SummariseGraze(const std::vector<TriGraze> &tris)
+{
+    MeshGraze out;
+    GrazeOfSet(0u, (uint32_t)tris.size(), [&tris](uint32_t k) -> const TriGraze & { return tris[k]; }, out.cone, out.reach);
+    return out;
 }
 
 void BuildGrazeNodes(const std::vector<BvhNode> &nodes, uint32_t root, uint32_t leaf_base, const std::vector<uint32_t> &order,

@@ -5,6 +5,7 @@
 // rounding error of those tests, so the closest hit found is the one the brute-force loops find.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -116,6 +117,17 @@ static_assert(sizeof(GrazeNode) == 16, "graze record is 16 bytes");
 // to box i of that call).  root is what BuildBvh returned.
 void BuildGrazeNodes(const std::vector<BvhNode> &nodes, uint32_t root, uint32_t leaf_base, const std::vector<uint32_t> &order,
                      const std::vector<TriGraze> &tris, std::vector<GrazeNode> &out);
+// The same two numbers for a whole mesh: what a ray is checked against when it enters the mesh's hierarchy.
+// A ray outside the mesh's band needs none of the above.  A ray inside it, with every triangle of the mesh
+// small (g < 0.05), is given ONE margin for all of the mesh's nodes, from the mesh's reach, which costs a
+// multiply-add per node visit; only a mesh with larger triangles makes the traversal look at the children's
+// own cones and reaches, node by node (evaluating those for every ray cost 16 % of a launch on the stress
+// scene, whose triangles are all small and whose white-noise heights leave no narrow cone anywhere).
+struct MeshGraze {
+    uint32_t cone = 0xFF000000u;
+    float reach = INFINITY;
+};
+MeshGraze SummariseGraze(const std::vector<TriGraze> &tris);
 // The threshold T of a cone word's code (for tests and for the builder's own rounding).
 float GrazeConeThreshold(uint32_t code);
 

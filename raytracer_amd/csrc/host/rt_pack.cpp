@@ -80,7 +80,8 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
     // applied by the traversal, relative to each ray.
     std::vector<rtmi::BvhNode> nodes;
     std::vector<rtmi::QNode> qnodes;   // what is uploaded: the nodes in their 32-byte form
-    std::vector<rtmi::GrazeNode> graze;  // one record per node of the meshes' hierarchies
+    std::vector<rtmi::MeshGraze> mesh_summary(nM);  // per mesh: cone and reach for rays along triangle planes
+    std::vector<rtmi::GrazeNode> graze;  // the same per child of every node of the meshes' hierarchies
     uint32_t graze_first = 0u;           // index of the first such node
     rtmi::QFrame qframe;
     float sphere_floor = 0.0f;
@@ -159,6 +160,7 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
                         tg[k] = rtmi::TriangleGraze(ab, ac, n);
                     }
                     rtmi::BuildGrazeNodes(mesh_nodes[m], mesh_root[m], leaf_base[m], mesh_order[m], tg, mesh_graze[m]);
+                    mesh_summary[m] = rtmi::SummariseGraze(tg);
                     for (uint32_t k = 0; k < count; k++) mesh_order[m][k] += start;
                 }
             };
@@ -231,7 +233,7 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
         off_btri = align_up(off_bsid + (size_t)nS * 4, 256);
         off_btid = align_up(off_btri + tri_order.size() * 64, 256);
         off_mroot = align_up(off_btid + tri_order.size() * 4, 256);
-        off_graze = align_up(off_mroot + (size_t)nM * 4, 256);
+        off_graze = align_up(off_mroot + (size_t)nM * 16, 256);
         total = align_up(off_graze + graze.size() * sizeof(rtmi::GrazeNode), 256) + 256;
     }
     std::vector<unsigned char> &blob = out.blob;
@@ -303,7 +305,14 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
             memcpy(bt + 16 * k, tri + 16 * (size_t)tri_order[k], 64);
             bj[k] = tri_order[k];
         }
-        if (nM) memcpy(blob.data() + off_mroot, mesh_root.data(), (size_t)nM * 4);
+        // per mesh {root reference, cone word, reach, 0}
+        uint32_t *mi = reinterpret_cast<uint32_t *>(blob.data() + off_mroot);
+        for (uint32_t m = 0; m < nM; m++) {
+            mi[4 * (size_t)m + 0] = mesh_root[m];
+            mi[4 * (size_t)m + 1] = mesh_summary[m].cone;
+            memcpy(&mi[4 * (size_t)m + 2], &mesh_summary[m].reach, 4);
+            mi[4 * (size_t)m + 3] = 0u;
+        }
         if (!graze.empty()) memcpy(blob.data() + off_graze, graze.data(), graze.size() * sizeof(rtmi::GrazeNode));
     }
 

@@ -62,7 +62,7 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
         (DS).bvh_sphere_id = (PK).bvh ? reinterpret_cast<const uint32_t *>(b_ + (PK).off_bsid) : nullptr;                  \
         (DS).bvh_tri_isect = (PK).bvh ? reinterpret_cast<const float4 *>(b_ + (PK).off_btri) : nullptr;                    \
         (DS).bvh_tri_id = (PK).bvh ? reinterpret_cast<const uint32_t *>(b_ + (PK).off_btid) : nullptr;                     \
-        (DS).bvh_mesh_root = (PK).bvh ? reinterpret_cast<const uint32_t *>(b_ + (PK).off_mroot) : nullptr;                 \
+        (DS).bvh_mesh_info = (PK).bvh ? reinterpret_cast<const uint4 *>(b_ + (PK).off_mroot) : nullptr;                    \
         (DS).bvh_sphere_root = (PK).sphere_root;                                                                           \
         (DS).bvh_node_count = (PK).bvh ? (PK).node_count : 0u;                                                             \
         (DS).bvh_graze = (PK).bvh ? reinterpret_cast<const uint4 *>(b_ + (PK).off_graze) : nullptr;                        \

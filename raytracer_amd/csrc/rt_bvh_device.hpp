@@ -17,8 +17,8 @@
 //   triangle  the numerators of u, v carry errors of about 8 ulp of |ao| |edge| |d|; in the triangle's
 //             plane that is a strip of width 8 * 2^-24 |ao| / cos(phi) around the triangle (phi the
 //             angle between ray and normal).  A margin of 2^-12 |ao| covers every ray that is more
-//             than 0.12 degrees off the triangle's plane; flatter rays are culled by the det >= 1e-6
-//             test for all but tiny triangles.
+//             than a fraction of a degree off the triangle's plane; flatter rays get a larger margin
+//             (bvh_graze_margin below).
 // Every box test grows the box by margin = sqrt(f^2 + kappa D^2) - f, where D^2 bounds |oc|^2 (|ao|^2)
 // for everything in the box (sum over the axes of the squared largest distance between ray origin
 // and box) and f is the smallest radius below the node (0 for triangles), plus 2^-19 of the largest
@@ -51,6 +51,7 @@ struct BvhWalk {
     Hit best;
     V3 inv;                  // 1 / d per component (Raytracing.comp:313-315)
     float a;                 // dot(d, d)
+    float gm;                // extra margin of the current mesh for this ray, per 2^-12 of the distance (0 in the sphere hierarchy)
     unsigned long long gates;  // bit b: the ray enters mesh gate_base + b and has not walked it yet
     uint32_t gate_base;      // first mesh of the current chunk of 64 gates
     uint32_t cur_mesh, ref, leaf_pos, leaf_left;
@@ -61,6 +62,8 @@ struct BvhWalk {
     static constexpr uint32_t kWalking = 2u;         // ref / leaf_left describe work inside the current group
     static constexpr uint32_t kInSpheres = 8u;       // the current group is the sphere hierarchy
     static constexpr uint32_t kOwnBest = 16u;        // best is a triangle of the current mesh
+    static constexpr uint32_t kGrazeNodes = 32u;     // the current mesh holds large triangles and the ray may run along
+                                                     // one: the children's own cones and reaches decide, node by node
     __device__ __forceinline__ bool is(uint32_t f) const { return (flags & f) != 0u; }
     __device__ __forceinline__ void set(uint32_t f) { flags |= f; }
     __device__ __forceinline__ void clear(uint32_t f) { flags &= ~f; }
@@ -104,6 +107,7 @@ __device__ __forceinline__ void bvh_idle(BvhWalk &w)
     w.best.v = 0.0f;
     w.inv = mk(0.0f, 0.0f, 0.0f);
     w.a = 0.0f;
+    w.gm = 0.0f;
     w.gates = 0ull;
     w.gate_base = 0u;
     w.cur_mesh = 0u;
@@ -125,6 +129,7 @@ __device__ __forceinline__ void bvh_begin(BvhWalk &w, const DeviceScene &sc, uin
     w.best.v = 0.0f;
     w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     w.a = dot(d, d);
+    w.gm = 0.0f;
     w.gate_base = 0u;
     w.gates = bvh_gates<COUNT, true>(sc, 0u, n_meshes, o, w.inv, cn);
     w.cur_mesh = 0u;
@@ -174,24 +179,49 @@ __device__ __forceinline__ bool bvh_at_inner(const BvhWalk &w)
 constexpr uint32_t kBvhUnbounded = 0x08000000u;
 constexpr uint32_t kBvhIndexMask = 0x07FFFFFFu;
 
-// One child of a triangle-hierarchy node and a ray that may run almost inside the plane of a triangle below
-// it.  word: the child's cone (axis as three int8, code byte); reach: eps 1e6 G of the largest triangle below.
-// A ray outside the cone's band keeps the usual margin e.  Inside the band the rounding of RayTriangle
-// (Raytracing.comp:286-309) can accept the ray up to 26 g / (1 - 2.25 g) of the distance away from the triangle,
-// g = reach |d|: the child is given that margin, at most `cap` of the distance; from g = 0.05 on (triangles
-// whose edges are about half a unit and longer) it is visited whatever its box says.
-__device__ __forceinline__ void bvh_graze_child(uint32_t word, float reach, V3 d, float dd, float dlen, float dist, float cap, float e,
-                                                float &e_child, bool &always)
+// Rays that run almost inside the plane of a triangle (host/rt_bvh.hpp has the derivation).  A set of
+// triangles (a mesh, or what lies below one child of a node) is described by a cone word (the axis of a cone
+// around their normals as three int8, and a code byte for its width) and a reach (eps 1e6 G of the largest
+// triangle of the set).  A ray outside the cone's band cannot be that flat to any triangle of the set: the
+// usual margin covers it.  Inside the band the rounding of RayTriangle (Raytracing.comp:286-309) can accept the
+// ray up to 26 g / (1 - 2.25 g) of the distance away from a triangle, g = reach |d|; from g = 0.05 on
+// (triangles whose edges are about half a unit and longer) that is the whole distance and more.
+__device__ __forceinline__ bool bvh_in_band(uint32_t word, V3 d, float dd)
 {
     const float ax = (float)((int)(word << 24) >> 24), ay = (float)((int)(word << 16) >> 24), az = (float)((int)(word << 8) >> 24);
     const uint32_t code = word >> 24;
     const float dq = __builtin_fmaf(d.z, az, __builtin_fmaf(d.y, ay, d.x * ax));
     const float T = __uint_as_float((code + 992u) << 20);
     // NaN compares false: such a ray counts as inside the band
-    const bool in_band = code == 255u || !(dq * dq > T * dd);
+    return code == 255u || !(dq * dq > T * dd);
+}
+
+// The ray enters a mesh's hierarchy: what it needs there.  Every triangle small (g < 0.05): ONE extra margin
+// for every box of the hierarchy, min(30 g, cap) of the distance, returned per 2^-12 of the distance (the
+// unit in which bvh_inner has the distance at hand); node_by_node stays false.  Otherwise the children's own
+// cones and reaches are consulted at every node (bvh_graze_child), so that a few large triangles do not open
+// the whole hierarchy to every ray.
+__device__ __forceinline__ float bvh_graze_enter(uint32_t word, float reach, V3 d, float dd, float cap, bool &node_by_node)
+{
+    node_by_node = false;
+    if (!bvh_in_band(word, d, dd)) return 0.0f;
+    // upper bound of |d| (hardware square root: 1 ulp)
+    const float g = reach * (__builtin_amdgcn_sqrtf(dd) * 1.000001f);
+    if (!(g < 0.05f)) {   // also when g is not a number
+        node_by_node = true;
+        return 0.0f;
+    }
+    return fminf(30.0f * g, cap) * 4096.01f;
+}
+
+// One child of a node of a mesh that is walked node by node: its margin e_child (the usual e outside the band),
+// or `always`: visited whatever its box says.
+__device__ __forceinline__ void bvh_graze_child(uint32_t word, float reach, V3 d, float dd, float dlen, float dist, float cap, float e,
+                                                float &e_child, bool &always)
+{
     e_child = e;
     always = false;
-    if (in_band) {
+    if (bvh_in_band(word, d, dd)) {
         const float g = reach * dlen;
         if (!(g < 0.05f)) always = true;
         else e_child = __builtin_fmaf(fminf(30.0f * g, cap), dist, e);
@@ -204,9 +234,10 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
 {
     const uint4 *__restrict__ rec = sc.bvh_nodes + 2 * (size_t)(w.ref & kBvhIndexMask);
     const uint4 n0 = rec[0], n1 = rec[1];
+    const bool TRI = !w.is(BvhWalk::kInSpheres);
     if (COUNT) cn.c[3] += 2u;
-    const float kappa = w.is(BvhWalk::kInSpheres) ? kBvhSphereKappa : kBvhTriangleKappa;
-    const float floor_r = w.is(BvhWalk::kInSpheres) ? sc.bvh_sphere_floor : 0.0f;
+    const float kappa = TRI ? kBvhTriangleKappa : kBvhSphereKappa;
+    const float floor_r = TRI ? 0.0f : sc.bvh_sphere_floor;
     const float t_limit = w.best.t * kBvhTSlack;
     const float cx = sc.bvh_base[0] - o.x, cy = sc.bvh_base[1] - o.y, cz = sc.bvh_base[2] - o.z;
     const float sx = sc.bvh_step[0], sy = sc.bvh_step[1], sz = sc.bvh_step[2];
@@ -225,12 +256,15 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
     // the hardware square root is good to 1 ulp; the factor 1 + 2^-20 keeps the result an upper bound
     const float grown = __builtin_amdgcn_sqrtf(__builtin_fmaf(kappa, d2, floor_r * floor_r)) * 1.00000095367431640625f;
     // 2^-19 of the largest distance component for the slab arithmetic, 2^-22 of it and the frame's slack for
-    // the planes themselves
-    const float e = __builtin_fmaf(2.1457672119140625e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r) + sc.bvh_slack;
-    // triangle hierarchies: the children's own margins for rays that may run inside a triangle's plane
+    // the planes themselves.  In a mesh's hierarchy `grown` is 2^-12 of (an upper bound of) the distance to
+    // anything below the node: the ray's margin for running along a triangle's plane, w.gm of those, comes on
+    // top (w.gm is 0 in the sphere hierarchy).
+    const float e = __builtin_fmaf(grown, w.gm, __builtin_fmaf(2.1457672119140625e-6f, fmaxf(fmaxf(mx, my), mz), grown - floor_r) + sc.bvh_slack);
+    // meshes with large triangles, rays that may run along one: the children's own margins.  No lane of a wave
+    // is in this state on scenes of small triangles, and the wave then skips the block.
     float el = e, er = e;
     bool always_l = false, always_r = false;
-    if (!w.is(BvhWalk::kInSpheres)) {
+    if (w.is(BvhWalk::kGrazeNodes)) {
         const uint4 gz = sc.bvh_graze[(w.ref & kBvhIndexMask) - sc.bvh_graze_first];
         // upper bounds of |d| and of the distance to anything below the node (hardware square root: 1 ulp)
         const float dlen = __builtin_amdgcn_sqrtf(w.a) * 1.000001f;
@@ -318,8 +352,12 @@ __device__ __forceinline__ void bvh_other(BvhWalk &w, const DeviceScene &sc, uin
             const uint32_t b = (uint32_t)__ffsll((long long)w.gates) - 1u;
             w.gates &= w.gates - 1ull;
             w.cur_mesh = w.gate_base + b;
-            w.clear(BvhWalk::kInSpheres | BvhWalk::kOwnBest);
-            w.ref = sc.bvh_mesh_root[w.cur_mesh];
+            w.clear(BvhWalk::kInSpheres | BvhWalk::kOwnBest | BvhWalk::kGrazeNodes);
+            const uint4 info = sc.bvh_mesh_info[w.cur_mesh];
+            w.ref = info.x;
+            bool node_by_node;
+            w.gm = bvh_graze_enter(info.y, __uint_as_float(info.z), d, w.a, sc.bvh_graze_cap, node_by_node);
+            if (node_by_node) w.set(BvhWalk::kGrazeNodes);
             if (w.ref == kBvhEmpty) {
                 bvh_group_done(w, n_meshes);
                 return;
@@ -409,7 +447,9 @@ __device__ __forceinline__ void bvh_other(BvhWalk &w, const DeviceScene &sc, uin
 // must call it, stepping or not.  The three kinds of step (inner node, sphere of a leaf, triangle of a
 // leaf or change of group) are different code, and a wave whose lanes want different kinds would run
 // all of it for every pass, most lanes idle in each part.  So a pass runs ONE kind: inner nodes while
-// enough lanes are at one, otherwise everything else for the lanes that have been waiting.
+// enough lanes are at one, otherwise everything else for the lanes that have been waiting.  (Inner nodes of
+// the meshes' hierarchies, which carry extra work for rays along triangle planes, were tried as part of
+// "everything else": 146 -> 174 ms per 16 frames of the stress scene, the lanes at such nodes wait too long.)
 template <bool COUNT>
 __device__ __forceinline__ void bvh_pass(bool stepping, BvhWalk &w, const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, V3 o,
                                          V3 d, Counters &cn, uint32_t *stack, uint32_t stride)

@@ -285,7 +285,8 @@ struct DeviceScene {
     const uint32_t *bvh_sphere_id;  // [S]      sphere index of each leaf-order entry
     const float4 *bvh_tri_isect;    // [L][4]   tri_isect in leaf order (L = sum of the meshes' counts)
     const uint32_t *bvh_tri_id;     // [L]      triangle index of each leaf-order entry
-    const uint32_t *bvh_mesh_root;  // [M]      root reference of each mesh's hierarchy
+    const uint4 *bvh_mesh_info;     // [M]      per mesh {root reference of its hierarchy, cone word, reach, 0}: the last two
+                                    //          for rays that run almost inside a triangle's plane (rt_bvh_device.hpp)
     uint32_t bvh_sphere_root;       // root reference of the sphere hierarchy
     uint32_t bvh_node_count;        // nodes in bvh_nodes (all hierarchies)
     // rays almost inside a triangle's plane: per node of the meshes' hierarchies {left cone, right cone,

@@ -263,8 +263,9 @@ class Renderer:
         self._check(self._lib.rtmi_set_acceleration(self._ctx, mode))
 
     def set_grazing_cap(self, cap):
-        """Largest margin (fraction of the distance) the hierarchy gives rays that run almost inside a
-        triangle's plane (rtmi_set_grazing_cap); 1.0 = the proven bound, whatever it costs."""
+        """Largest extra margin (fraction of the distance) the boxes of a mesh of small triangles are given for
+        a ray that runs almost inside a triangle's plane (rtmi_set_grazing_cap); 0 = none, 1.0 = the proven
+        bound, whatever it costs.  A kernel argument: applies from the next launch on."""
         self._check(self._lib.rtmi_set_grazing_cap(self._ctx, float(cap)))
 
     def grazing_cap(self):

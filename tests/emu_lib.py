@@ -28,7 +28,7 @@ def lib(kind="strict"):
     return _libs[kind]
 
 
-def closest_hit(scene, origins, directions, use_bvh, cap=2.0 ** -7, kind="strict"):
+def closest_hit(scene, origins, directions, use_bvh, cap=2.0 ** -9, kind="strict"):
     """(t, prim) per ray of a raytracer_amd.Scene: through the hierarchy (use_bvh) or the exhaustive loops."""
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)

@@ -43,8 +43,11 @@ def _scenes_and_rays(n):
     import grazing_rate as G
     rs = np.random.RandomState(21)
     out = []
+    small = G.big_triangles(rs, 500, (0.05, 0.4))
+    mixed = np.concatenate([small[:250], G.big_triangles(rs, 20), small[250:]])   # a few large triangles among small ones
     for name, tri in (("noisy_grid", G.noisy_grid(rs, 40, 20)), ("big_triangles", G.big_triangles(rs, 150)),
-                      ("mid_triangles", G.big_triangles(rs, 400, (0.3, 2.0))), ("small_triangles", G.big_triangles(rs, 800, (0.05, 0.4)))):
+                      ("mid_triangles", G.big_triangles(rs, 400, (0.3, 2.0))), ("small_triangles", G.big_triangles(rs, 800, (0.05, 0.4))),
+                      ("mixed", mixed)):
         sc = G.one_mesh_scene(tri)
         rays = [gen(rs, tri, n) for gen in (G.rays_uniform, G.rays_far, G.rays_grazing)]
         out.append((name, sc, np.concatenate([r[0] for r in rays]), np.concatenate([r[1] for r in rays])))
@@ -94,4 +97,4 @@ def test_traversal_under_address_sanitizer(rtmi_host):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.strip().splitlines()
-    assert len(lines) == 5 and all(line.split()[1] == "0" for line in lines), out.stdout
+    assert len(lines) == 6 and all(line.split()[1] == "0" for line in lines), out.stdout
