@@ -273,7 +273,9 @@ __device__ __forceinline__ void bvh_inner(BvhWalk &w, const DeviceScene &sc, uin
         bvh_graze_child(gz.y, __uint_as_float(gz.w), d, w.a, dlen, dist, sc.bvh_graze_cap, e, er, always_r);
     }
     // Entry and exit distances of the grown boxes.  NaN (0 * inf, inf - inf) makes a comparison false,
-    // which keeps the box.
+    // which keeps the box.  (The margin is applied to the plane, not to the quotient: folded into one fused
+    // multiply-add per plane, plane / d -+ margin / d, a direction component of exactly 0 turns a ray origin
+    // inside the margin into inf - inf, and the minimum of that NaN and the other plane's infinity culls the box.)
     const V3 inv = w.inv;
     const float a1 = (l0x - el) * inv.x, a2 = (l1x + el) * inv.x;
     const float a3 = (l0y - el) * inv.y, a4 = (l1y + el) * inv.y;

@@ -374,14 +374,14 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
         // (a discriminant below 2^-96 is outside the short square root's range: such a ray goes through the
         // literal evaluation below)
         auto candidate = [&](float b, float disc, uint32_t i) {
-#ifdef RT_PATHS_PROFILE
+#if defined(RT_PATHS_PROFILE) && RT_PATHS_PROFILE != 2
             {
                 const unsigned long long m = __ballot(disc >= 0.0f && b < 0.0f);
                 if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) cn.c[12]++;  // block runs
             }
 #endif
             if (disc >= 0.0f && b < 0.0f) {
-#ifdef RT_PATHS_PROFILE
+#if defined(RT_PATHS_PROFILE) && RT_PATHS_PROFILE != 2
                 cn.c[11]++;
 #endif
                 ambiguous = ambiguous || !sqrt_rn_admits(disc);
@@ -433,7 +433,7 @@ __device__ __forceinline__ Hit closest_hit_spheres(const DeviceScene &sc, uint32
             best.mat = best_i;
             ambiguous = ambiguous || !(best.t < kFltMax);
         }
-#ifdef RT_PATHS_PROFILE
+#if defined(RT_PATHS_PROFILE) && RT_PATHS_PROFILE != 2
         {
             const unsigned long long m = __ballot(ambiguous);
             if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) cn.c[14]++;
