@@ -210,8 +210,11 @@ RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
  * live in a static device array inside the library (4 bytes per pixel + 256 bytes, held by every GPU
  * the library runs on until the process ends) instead of buffers of the context, so the image may
  * hold at most RTMI_NOALLOC_MAX_PIXELS pixels (RTMI_ERR_UNSUPPORTED beyond that, and with validation
- * outputs enabled).  All contexts on one GPU share that array: no-allocation calls on the same GPU
- * must not overlap (same stream, or otherwise ordered), or they race.  The kernel choice is that of
+ * outputs enabled).  All contexts on one GPU share that array.  The library orders its users: every
+ * no-allocation launch records an event of its context (created with the context), and the next one on that
+ * GPU, if it runs on another stream, waits for it on the device first; so contexts on their own streams may
+ * call in any order without synchronising, and simply take turns.  (A caller that puts several contexts on
+ * the SAME stream handle it passed in gets the stream's own order.)  The kernel choice is that of
  * rtmi_set_variant, except that primary segments are never kept between launches. */
 #define RTMI_NOALLOC_MAX_PIXELS 2097152u   /* 2^21: covers 1920 x 1080; 8 MiB of device memory per GPU */
 RTMI_API int rtmi_render_frames_noalloc(rtmi_ctx *ctx, const rtmi_frame_data *fd,
@@ -366,6 +369,13 @@ RTMI_API int rtmi_scene_load(const char *path, rtmi_sphere *spheres, uint32_t *n
  * No counterpart in the reference. */
 RTMI_API int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nodes_out, size_t nodes_bytes,
                             uint32_t *order_out, uint32_t *root_out);
+/* The second step of the upload, also callable on its own: n_nodes 64-byte nodes as rtmi_bvh_build writes them
+ * become the 32-byte nodes the kernels walk, {left ref, right ref, left box x y z, right box x y z}, every box
+ * axis a pair of 16-bit step counts lower | upper << 16 in the frame written to frame_out (origin x y z, step
+ * x y z): plane = origin + count * step, lower planes rounded down and upper planes up.  A child whose box has
+ * an infinite or out-of-frame bound gets bit 27 of its reference set (always visited).  Returns n_nodes.
+ * No counterpart in the reference. */
+RTMI_API int rtmi_bvh_quantize(const void *nodes, uint32_t n_nodes, void *qnodes_out, size_t qnodes_bytes, float *frame_out);
 
 /* Constants of main.cpp:116-123, 151-153 (rays_per_pixel 4, max bounces 6, sky / sun / ground). */
 RTMI_API void rtmi_default_frame_data(rtmi_frame_data *fd);

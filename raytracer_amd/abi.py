@@ -157,6 +157,7 @@ PROTOTYPES = {
                                   C.POINTER(Mesh), C.POINTER(C.c_uint32), C.c_uint32]),
     "rtmi_bvh_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.POINTER(C.c_uint32)]),
+    "rtmi_bvh_quantize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtmi_default_frame_data": (None, [C.POINTER(FrameData)]),
     "rtmi_camera_init": (None, [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
     "rtmi_camera_set_pose": (None, [C.POINTER(Camera), _f, C.c_float, C.c_float]),

@@ -159,6 +159,30 @@ int rtmi_bvh_build(const float *boxes, uint32_t n, uint32_t leaf_base, void *nod
     }
 }
 
+int rtmi_bvh_quantize(const void *nodes, uint32_t n_nodes, void *qnodes_out, size_t qnodes_bytes, float *frame_out)
+{
+    if ((n_nodes && !nodes) || (n_nodes && !qnodes_out) || !frame_out) return RTMI_ERR_INVALID_ARGUMENT;
+    if ((size_t)n_nodes * sizeof(rtmi::QNode) > qnodes_bytes) return RTMI_ERR_OUT_OF_MEMORY;
+    try {
+        std::vector<rtmi::BvhNode> in(n_nodes);
+        if (n_nodes) std::memcpy(in.data(), nodes, (size_t)n_nodes * sizeof(rtmi::BvhNode));
+        std::vector<rtmi::QNode> q;
+        rtmi::QFrame fr;
+        rtmi::QuantizeNodes(in, fr, q);
+        if (q.size() != n_nodes) return RTMI_ERR_UNSUPPORTED;
+        if (n_nodes) std::memcpy(qnodes_out, q.data(), (size_t)n_nodes * sizeof(rtmi::QNode));
+        for (int a = 0; a < 3; a++) {
+            frame_out[a] = fr.origin[a];
+            frame_out[3 + a] = fr.step[a];
+        }
+        return (int)n_nodes;
+    } catch (const std::bad_alloc &) {
+        return RTMI_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RTMI_ERR_UNSUPPORTED;
+    }
+}
+
 int rtmi_scene_save(const char *path, const rtmi_sphere *spheres, uint32_t n_spheres, const rtmi_triangle *triangles,
                     uint32_t n_triangles, const rtmi_mesh *meshes, uint32_t n_meshes)
 {

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64) void k_selftest_env(const RenderParams p, const
     __shared__ float mail[kSkyMail];
     const Sky sky = make_sky(p);
     const uint32_t lane = threadIdx.x;
-    // 42 directions per workgroup in the wave form (lanes 2, 5, 8, ... idle), 64 otherwise
+    // 43 directions per workgroup in the wave form (lanes 2, 5, 8, ... 62 idle), 64 otherwise
     const bool idle = wave_form && lane % 3u == 2u;
     const size_t per_group = wave_form ? 43u : 64u;
     const size_t i = (size_t)blockIdx.x * per_group + (wave_form ? lane - lane / 3u : lane);

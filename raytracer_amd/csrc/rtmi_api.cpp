@@ -44,6 +44,7 @@ struct rtmi_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_noalloc = nullptr;   // recorded after every no-allocation launch (orders the users of the static work area)
     bool timed = false;
     // launch timing log: one event pair per render call since the last rtmi_timing_reset
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -92,6 +93,18 @@ constexpr uint32_t kScratchHeadWords = 64u;
 static __device__ __align__(256) uint32_t scratch[kScratchHeadWords + kNoAllocMaxPixels];
 
 namespace {
+
+// The last no-allocation launch on each device: the next one, if it runs on another stream, first waits for
+// that launch's event (created with its context, so nothing is allocated here), which orders the users of
+// the device's one work area whatever streams their contexts use.
+struct ScratchUser {
+    rtmi_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+constexpr int kMaxDevices = 64;
+ScratchUser g_scratch_user[kMaxDevices];
+std::mutex g_scratch_lock;
 
 thread_local std::string g_create_error;
 
@@ -190,6 +203,7 @@ int rtmi_create(int device, uint32_t width, uint32_t height, rtmi_ctx **out)
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_noalloc, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     const size_t np = n_pixels(c);
     if ((e = hipMalloc(&c->own_accum, np * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
     c->accum = c->own_accum;
@@ -211,6 +225,16 @@ int rtmi_destroy(rtmi_ctx *c)
     if (!c) return RTMI_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->device >= 0 && c->device < kMaxDevices) {
+        // the work area's last user, if it is this context, has finished once its stream has drained
+        std::lock_guard<std::mutex> guard(g_scratch_lock);
+        ScratchUser &u = g_scratch_user[c->device];
+        if (u.ctx == c) {
+            if (u.stream != c->own_stream && u.done) (void)hipEventSynchronize(u.done);
+            u = ScratchUser();
+        }
+    }
+    if (c->ev_noalloc) (void)hipEventDestroy(c->ev_noalloc);
     (void)hipFree(c->own_accum);
     (void)hipFree(c->out_rgba8);
     (void)hipFree(c->hit_ids);
@@ -424,8 +448,24 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
             return fail(c, RTMI_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
         }
     }
-    hipError_t e = c->fused ? rt_launch_render_fma(variant, c->validate, p, c->stream, cache)
-                           : rt_launch_render(variant, c->validate, p, c->stream, cache);
+    hipError_t e = hipSuccess;
+    if (no_alloc) {
+        // one work area per device: wait for its previous user unless that was this very stream
+        if (c->device >= kMaxDevices) return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render_frames_noalloc: device %d beyond %d", c->device, kMaxDevices);
+        std::lock_guard<std::mutex> guard(g_scratch_lock);
+        ScratchUser &u = g_scratch_user[c->device];
+        if (u.ctx && u.stream != c->stream) e = hipStreamWaitEvent(c->stream, u.done, 0);
+        if (e == hipSuccess)
+            e = c->fused ? rt_launch_render_fma(variant, c->validate, p, c->stream, cache) : rt_launch_render(variant, c->validate, p, c->stream, cache);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_noalloc, c->stream);
+        if (e == hipSuccess) {
+            u.ctx = c;
+            u.stream = c->stream;
+            u.done = c->ev_noalloc;
+        }
+    } else {
+        e = c->fused ? rt_launch_render_fma(variant, c->validate, p, c->stream, cache) : rt_launch_render(variant, c->validate, p, c->stream, cache);
+    }
     if (e != hipSuccess) {
         drop_store();
         return fail(c, RTMI_ERR_HIP, "kernel launch (%s) failed: %s", rt_kernel_name(variant), hipGetErrorString(e));

@@ -120,3 +120,71 @@ def test_margin_floor_is_the_smallest_below(rtmi):
     nodes, _, _ = build(rtmi, boxes)
     f = nodes.view(np.float32)
     assert (f[:, 11] == 0).all() and (f[:, 15] == 0).all()
+
+
+def quantize(rtmi, nodes):
+    lib = rtmi.abi.load()
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 16)
+    q = np.zeros((max(1, len(nodes)), 8), dtype=np.uint32)
+    frame = np.zeros(6, dtype=np.float32)
+    rc = lib.rtmi_bvh_quantize(nodes.ctypes.data, len(nodes), q.ctypes.data, q.nbytes, frame.ctypes.data)
+    assert rc == len(nodes)
+    return q[:len(nodes)], frame[:3].astype(np.float64), frame[3:].astype(np.float64)
+
+
+def _child_boxes(node_words):
+    f = node_words.view(np.float32)
+    return (f[0:3], f[4:7]), (f[8:11], f[12:15])
+
+
+def test_quantised_boxes_enclose_the_float_boxes(rtmi):
+    rs = np.random.RandomState(4)
+    c = rs.uniform(-40, 60, size=(3000, 3))
+    r = rs.uniform(0.01, 0.5, size=(3000, 1))
+    boxes = np.concatenate([c - r, c + r], axis=1).astype(np.float32)
+    nodes, _, _ = build(rtmi, boxes)
+    q, origin, step = quantize(rtmi, nodes)
+    assert (q[:, 0] & 0x87FFFFFF == nodes[:, 3] & 0x87FFFFFF).all() and (q[:, 1] & 0x87FFFFFF == nodes[:, 7] & 0x87FFFFFF).all()
+    assert not (q[:, :2] & 0x08000000).any()                       # every box finite and inside the frame
+    for i in range(len(nodes)):
+        for side, (lo, hi) in enumerate(_child_boxes(nodes[i])):
+            w = q[i, 2 + 3 * side: 5 + 3 * side]
+            qlo = origin + (w & 0xFFFF).astype(np.float64) * step
+            qhi = origin + (w >> 16).astype(np.float64) * step
+            assert (qlo <= lo.astype(np.float64)).all() and (qhi >= hi.astype(np.float64)).all()
+            assert ((lo.astype(np.float64) - qlo) <= 2.5 * step).all() and ((qhi - hi.astype(np.float64)) <= 2.5 * step).all()
+
+
+def test_quantise_infinite_inverted_and_degenerate_boxes(rtmi):
+    """Boxes with infinite bounds (an infinite-radius sphere), an inverted box (a child without finite primitives),
+    a NaN bound (which the builder never stores and the quantiser reads as "no primitives"), a point box and a box
+    of astronomic extent: none of them may reach an integer conversion unchecked (this entry point runs under UBSan
+    in the sanitizer build), children with an infinite plane are flagged as always visited, and the finite ones
+    still enclose."""
+    inf, nan = np.inf, np.nan
+    node = np.zeros((4, 16), dtype=np.uint32)
+    f = node.view(np.float32)
+
+    def put(i, l_lo, l_hi, r_lo, r_hi):
+        f[i, 0:3], f[i, 4:7], f[i, 8:11], f[i, 12:15] = l_lo, l_hi, r_lo, r_hi
+        node[i, 3], node[i, 7] = 0x90000000 | (2 * i), 0x90000000 | (2 * i + 1)   # leaves of one primitive
+
+    put(0, (-1, -1, -1), (1, 1, 1), (-inf, -inf, -inf), (inf, inf, inf))           # finite | infinite
+    put(1, (2, 2, 2), (2, 2, 2), (3.4e38, 0, 0), (-3.4e38, 0, 0))                  # a point | inverted
+    put(2, (nan, 0, 0), (1, 1, 1), (-5, -5, -5), (5, 5, 5))                        # NaN bound | finite
+    put(3, (-1e30, 0, 0), (1e30, 1, 1), (0, 0, 0), (0.5, inf, 0.5))                # huge but finite | one infinite plane
+    q, origin, step = quantize(rtmi, node)
+    flag = 0x08000000
+    assert not q[0, 0] & flag and q[0, 1] & flag
+    assert not q[1, 0] & flag
+    assert not q[2, 0] & flag and not q[2, 1] & flag
+    for w in list(q[1, 5:8]) + list(q[2, 2:5]):                    # inverted and NaN children: lower 0xFFFF, upper 0
+        assert int(w) == 0x0000FFFF
+    assert q[3, 1] & flag
+    assert np.isfinite(origin).all() and np.isfinite(step).all() and (step > 0).all()
+    for i, side in ((0, 0), (1, 0), (2, 1), (3, 0)):
+        lo, hi = _child_boxes(node[i])[side]
+        w = q[i, 2 + 3 * side: 5 + 3 * side]
+        qlo = origin + (w & 0xFFFF).astype(np.float64) * step
+        qhi = origin + (w >> 16).astype(np.float64) * step
+        assert (qlo <= lo.astype(np.float64)).all() and (qhi >= hi.astype(np.float64)).all()

@@ -23,7 +23,7 @@ def test_host_and_oracle_are_clean_under_sanitizers():
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_sanitizers.sh"), "quick"], capture_output=True, text=True,
                          timeout=600)
     logs = ""
-    for name in ("r02_sanitizers_asan.log", "r02_sanitizers_tsan.log"):
+    for name in ("r03_sanitizers_asan.log", "r03_sanitizers_tsan.log"):
         with open(os.path.join(os.environ.get("TMPDIR") or "/tmp", name)) as f:   # where the quick mode writes
             logs += f.read()[-1500:]
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:] + logs

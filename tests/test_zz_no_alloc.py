@@ -61,6 +61,36 @@ def test_hierarchy_scene_and_continued_sum(rtmi):
     assert cases.bits_equal(got, cases.load_golden("reference_defaults_rpp4_continue")["accum"])
 
 
+def test_two_contexts_on_their_own_streams_share_the_work_area_in_turn(rtmi):
+    """Two contexts on one GPU, each on its own stream, call the no-allocation entry point back to back with no host
+    synchronisation in between (20 rounds, the launches of one round queued before either has finished): the
+    library orders the users of the device's one work area itself, so both images must come out as from the
+    plain entry point."""
+    a = cases.CASES["c2_spheres_bench_pose"]
+    b = cases.CASES["c3_mesh_bench_pose"]
+    sa, sb = cases.product_scene(a), cases.product_scene(b)
+    size_a, size_b = (320, 180), (200, 120)
+    fda = rtmi.make_frame_data(size_a[0], size_a[1], sa, rtmi.BENCH_POSE, 1, 8)
+    fdb = rtmi.make_frame_data(size_b[0], size_b[1], sb, rtmi.BENCH_POSE, 1, 8)
+    rounds, per = 20, 8
+    want = []
+    for (size, sc, fd) in ((size_a, sa, fda), (size_b, sb, fdb)):
+        with rtmi.Renderer(size[0], size[1], variant=2) as r:
+            r.upload_scene(sc)
+            for k in range(rounds):
+                r.render_frames(fd, 1 + k * per, per)
+            want.append(r.read_accum())
+    with rtmi.Renderer(size_a[0], size_a[1], variant=2) as ra, rtmi.Renderer(size_b[0], size_b[1], variant=2) as rb:
+        ra.upload_scene(sa)
+        rb.upload_scene(sb)
+        for k in range(rounds):
+            ra.render_frames_noalloc(fda, 1 + k * per, per)
+            rb.render_frames_noalloc(fdb, 1 + k * per, per)
+        got = [ra.read_accum(), rb.read_accum()]
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
 def test_limits_and_errors(rtmi):
     a = rtmi.abi
     case = cases.CASES["c3_mesh_bench_pose"]
