@@ -330,6 +330,13 @@ RTMI_API int rtmi_selftest_exhaustive(rtmi_ctx *ctx, int op, float divisor, uint
 RTMI_API int rtmi_selftest_closest_hit(rtmi_ctx *ctx, uint32_t sphere_number, uint32_t mesh_number,
                                        const float *origins, const float *directions, size_t n,
                                        float *t_out, uint32_t *prim_out);
+/* The same question, for a scene with a hierarchy, answered by a kernel that does nothing but walk: persistent
+ * waves whose lanes take ray after ray (in the order given) and resume their walks as the path kernels do.  Same
+ * results; *ms_out receives the shortest of `repeats` launches.  A measurement hook: what the walks of a set of
+ * rays cost in a given order, without shading, queues or sorting.  No counterpart in the reference. */
+RTMI_API int rtmi_selftest_walk(rtmi_ctx *ctx, uint32_t sphere_number, uint32_t mesh_number, const float *origins,
+                                const float *directions, size_t n, uint32_t repeats, float *t_out, uint32_t *prim_out,
+                                float *ms_out);
 
 /* ------------------------------------------------------------------------------------------
  * Host side kept from the reference (C wrappers over the C++ classes of the same names).

@@ -880,7 +880,73 @@ __global__ __launch_bounds__(kBlockThreads) void k_selftest_hit(DeviceScene sc, 
     prim_out[i] = h.prim;
 }
 
+// ClosestHit of n arbitrary rays through the hierarchy the way the path kernels walk it: persistent waves, a
+// lane takes ray after ray from a launch-wide cursor and resumes its walk (bvh_pass), the wave leaves the
+// stepping loop when half of its walks are over.  Nothing but traversal: what the walks of a given set of
+// rays cost in a given ORDER (measurement hook; same results as k_selftest_hit).  *cursor must be zero at launch.
+__global__ __launch_bounds__(kStreamThreads, RT_STREAM_MIN_WAVES_LARGE) void k_selftest_walk(DeviceScene sc, uint32_t n_spheres, uint32_t n_meshes,
+                                                                                           const float *__restrict__ origins,
+                                                                                           const float *__restrict__ dirs, uint32_t n,
+                                                                                           float *__restrict__ t_out, uint32_t *__restrict__ prim_out,
+                                                                                           uint32_t *cursor)
+{
+    constexpr bool BVH = true;
+    RT_BVH_STACK(kStreamThreads);
+    const uint32_t lane = threadIdx.x;
+    Counters cn;
+    zero(cn);
+    BvhWalk walk;
+    bvh_idle(walk);
+    bool has_ray = false, exhausted = false;
+    uint32_t ray = 0u;
+    V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
+    for (;;) {
+        const unsigned long long need = __ballot(!has_ray);
+        if (need != 0ull && !exhausted) {
+            const uint32_t want = (uint32_t)__popcll(need);
+            uint32_t first = 0u;
+            if (lane == 0u) first = atomicAdd(cursor, want);
+            first = (uint32_t)__shfl((int)first, 0, 64);
+            exhausted = first + want >= n || first + want < first;
+            const uint32_t item = first + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!has_ray && item < n && item >= first) {
+                ray = item;
+                has_ray = true;
+                o = mk(origins[3 * (size_t)item], origins[3 * (size_t)item + 1], origins[3 * (size_t)item + 2]);
+                d = mk(dirs[3 * (size_t)item], dirs[3 * (size_t)item + 1], dirs[3 * (size_t)item + 2]);
+                bvh_begin<false>(walk, sc, n_spheres, n_meshes, o, d, cn);
+            }
+        }
+        const uint32_t holding = (uint32_t)__popcll(__ballot(has_ray));
+        if (holding == 0u) {
+            if (exhausted) break;
+            continue;
+        }
+        const uint32_t target = (holding * RT_BVH_KEEP_NUM) >> RT_BVH_KEEP_SHIFT;
+        for (;;) {
+            const bool stepping = has_ray && walk.active();
+            if ((uint32_t)__popcll(__ballot(stepping)) <= target) break;
+            bvh_pass<false>(stepping, walk, sc, n_spheres, n_meshes, o, d, cn, bvh_stack, bvh_stride);
+        }
+        if (has_ray && !walk.active()) {
+            t_out[ray] = walk.best.t;
+            prim_out[ray] = walk.best.prim;
+            has_ray = false;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t RT_SYM(rt_launch_selftest_walk)(const DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins, const float *dirs,
+                                           uint32_t n, float *t_out, uint32_t *prim_out, uint32_t *cursor, uint32_t n_cus, hipStream_t stream)
+{
+    const uint32_t cus = n_cus ? n_cus : 256u;
+    const dim3 grid(cus * 4u * RT_STREAM_MIN_WAVES_LARGE, 1, 1);
+    hipLaunchKernelGGL(k_selftest_walk, grid, dim3(kStreamThreads, 1, 1), 0, stream, sc, n_spheres, n_meshes, origins, dirs, n, t_out, prim_out,
+                       cursor);
+    return hipGetLastError();
+}
 
 hipError_t RT_SYM(rt_launch_selftest_hit)(const DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes, const float *origins,
                                   const float *dirs, size_t n, float *t_out, uint32_t *prim_out, hipStream_t stream)

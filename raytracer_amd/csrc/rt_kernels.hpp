@@ -58,6 +58,9 @@ enum RtCacheUse {
     hipError_t rt_launch_selftest_hit##S(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes,             \
                                          const float *origins, const float *dirs, size_t n, float *t_out, uint32_t *prim_out,         \
                                          hipStream_t stream);                                                                         \
+    hipError_t rt_launch_selftest_walk##S(const rtd::DeviceScene &sc, uint32_t n_spheres, uint32_t n_meshes, const float *origins,          \
+                                          const float *dirs, uint32_t n, float *t_out, uint32_t *prim_out, uint32_t *cursor,            \
+                                          uint32_t n_cus, hipStream_t stream);                                                         \
     hipError_t rt_launch_selftest_env##S(const RenderParams &p, const float *dirs, size_t n, int wave_form, float *rgb_out,           \
                                          hipStream_t stream);                                                                         \
     hipError_t rt_launch_selftest_exhaustive##S(int op, float c, unsigned long long *out, hipStream_t stream);                        \

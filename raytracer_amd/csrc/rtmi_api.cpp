@@ -1021,4 +1021,55 @@ int rtmi_selftest_closest_hit(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh
     return rc;
 }
 
+// The same rays through the walk-only streaming kernel, timed: `repeats` launches, the shortest in *ms_out.
+int rtmi_selftest_walk(rtmi_ctx *c, uint32_t sphere_number, uint32_t mesh_number, const float *origins, const float *directions,
+                       size_t n, uint32_t repeats, float *t_out, uint32_t *prim_out, float *ms_out)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    if (!origins || !directions || !t_out || !prim_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_selftest_walk: NULL argument");
+    if (!c->has_scene || !c->bvh_active) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_selftest_walk: no scene with a hierarchy uploaded");
+    if (sphere_number > c->n_spheres || mesh_number > c->n_meshes)
+        return fail(c, RTMI_ERR_SCENE_MISMATCH, "rtmi_selftest_walk: counts exceed the uploaded scene");
+    if (n == 0) return RTMI_OK;
+    if (n > 0x7FFFFFFFull) return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_selftest_walk: at most 2^31 - 1 rays");
+    if (repeats == 0) repeats = 1;
+    if (int rc = use_device(c)) return rc;
+    float *dbuf = nullptr;
+    int rc = RTMI_OK;
+    // one allocation: origins | directions | t | prim | cursor
+    hipError_t e = hipMalloc(&dbuf, n * 8 * sizeof(float) + 256);
+    if (e != hipSuccess || !dbuf)
+        return fail(c, e == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP, "rtmi_selftest_walk: hipMalloc: %s", hipGetErrorString(e));
+    float *d_o = dbuf, *d_d = dbuf + 3 * n, *d_t = dbuf + 6 * n;
+    uint32_t *d_p = reinterpret_cast<uint32_t *>(dbuf + 7 * n);
+    uint32_t *d_cursor = reinterpret_cast<uint32_t *>(dbuf + 8 * n);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
+    float best = 0.0f;
+    for (uint32_t r = 0; r < repeats && e == hipSuccess; r++) {
+        e = hipMemsetAsync(d_cursor, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess)
+            e = c->fused ? rt_launch_selftest_walk_fma(c->dscene, sphere_number, mesh_number, d_o, d_d, (uint32_t)n, d_t, d_p, d_cursor, (uint32_t)c->n_cus, c->stream)
+                         : rt_launch_selftest_walk(c->dscene, sphere_number, mesh_number, d_o, d_d, (uint32_t)n, d_t, d_p, d_cursor, (uint32_t)c->n_cus, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && (r == 0 || ms < best)) best = ms;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_out, d_p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, RTMI_ERR_HIP, "rtmi_selftest_walk: %s", hipGetErrorString(e));
+    if (ms_out) *ms_out = best;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dbuf);
+    return rc;
+}
+
 }  // extern "C"

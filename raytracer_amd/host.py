@@ -375,6 +375,18 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
+    def selftest_walk(self, sphere_number, mesh_number, origins, directions, repeats=1):
+        """(t, prim_id, ms): the rays, in the order given, through the walk-only streaming kernel (hierarchy scenes)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        t = np.empty(len(o), dtype=np.float32)
+        prim = np.empty(len(o), dtype=np.uint32)
+        ms = C.c_float(0.0)
+        self._check(self._lib.rtmi_selftest_walk(self._ctx, sphere_number, mesh_number, o.ctypes.data, d.ctypes.data, len(o),
+                                                 repeats, t.ctypes.data, prim.ctypes.data, C.byref(ms)))
+        return t, prim, float(ms.value)
+
     def selftest_env_light(self, fd, directions, wave_form):
         """Sky radiance [n, 3] of directions [n, 3] under fd's sky constants; wave_form picks the routine."""
         d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)

@@ -261,3 +261,21 @@ def test_full_size_stress_scene(rtmi, oracle):
             r.render_frames(fd, 1, 2)
             big[variant] = (r.read_accum(), r.read_output_rgba8())
     assert cases.bits_equal(big[2][0], big[4][0]) and np.array_equal(big[2][1], big[4][1])
+
+
+def test_walk_only_streaming_kernel_returns_the_same_hits(rtmi):
+    """rtmi_selftest_walk (the measurement hook that walks rays through persistent waves with resumable walks, as
+    the path kernels do) against rtmi_selftest_closest_hit, ray by ray; more rays than one round of the device's
+    wave slots holds, and a count that is not a multiple of the wave size."""
+    sc, _ = rtmi.scenes.stress_scene(4000, (40, 40), 3, seed=8, extent=4.0)
+    rs = np.random.RandomState(12)
+    n = 64 * 6144 + 37
+    o = rs.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    d = (rs.normal(size=(n, 3)) * rs.uniform(0.3, 1.4, size=(n, 1))).astype(np.float32)
+    with rtmi.Renderer(8, 8) as r:
+        r.set_acceleration(rtmi.abi.ACCEL_BVH)
+        r.upload_scene(sc)
+        t0, q0 = r.selftest_closest_hit(sc.n_spheres, sc.n_meshes, o, d)
+        t1, q1, ms = r.selftest_walk(sc.n_spheres, sc.n_meshes, o, d, repeats=2)
+    assert (q0 != rtmi.abi.MISS_ID).mean() > 0.3 and ms > 0.0
+    assert np.array_equal(q0, q1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
