@@ -43,6 +43,9 @@ WORKLOADS = {
     "c1_plumbing": ("reference", 640, 360, 4),
     # 10^6 spheres + 10^6 triangles (generated, seed 12345), traced through the hierarchy
     "c5_stress": ("stress", 1920, 1080, 16),
+    # the same scene with every fourth sphere and mesh strip transmitting (index of refraction 1.5): an EXTENSION,
+    # the reference has no such material (Raytracing.comp:26-34); no parity target, reported separately from c5_stress
+    "c5_stress_glass": ("stress_glass", 1920, 1080, 16),
 }
 
 
@@ -50,6 +53,8 @@ def build_scene(R, scene_name):
     """(product scene, camera pose) of a workload."""
     if scene_name == "stress":
         return R.scenes.stress_scene()
+    if scene_name == "stress_glass":
+        return R.scenes.stress_scene(glass=True)
     return (R.sphere_scene() if scene_name == "spheres" else R.reference_scene()), R.BENCH_POSE
 
 
@@ -68,10 +73,11 @@ def cpu_baseline(workload, frames_hint, budget_s, profile="strict"):
     # stated through OMP_NUM_THREADS (a GPU box shows every CPU of the host to each of its jobs)
     omp = os.environ.get("OMP_NUM_THREADS", "")
     cores = max(1, min(affinity, int(omp)) if omp.isdigit() and int(omp) > 0 else affinity)
-    if scene_name == "stress":
+    if scene_name.startswith("stress"):
         import raytracer_amd as R
         psc, pose = build_scene(R, scene_name)
         sc = O.Scene.from_product(psc)
+        O.lib(profile).orc_set_transmission(1 if scene_name == "stress_glass" else 0)
         # the exhaustive loops cost about 0.1 s per pixel here, and the oracle's threads split image rows:
         # the sample is the same view rendered at 64x36 (one path per 30x30 block of the benchmark's pixels)
         sw, sh = 64, 36
@@ -174,12 +180,14 @@ def main():
     scene_name, width, height, max_bounce = WORKLOADS[args.workload]
     if args.variant is None:
         args.variant = 4 if args.workload.startswith("c5") else 2
-    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 16}.get(args.workload, 256)
+    frames = args.frames or {"c4_mesh_4k": 512, "c1_plumbing": 64, "c5_stress": 16, "c5_stress_glass": 16}.get(args.workload, 256)
     scene, pose = build_scene(R, scene_name)
     fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
     total_frames = frames * world
 
     renderer = R.Renderer(width, height, device=local_rank, variant=args.variant, profile=args.profile)
+    if scene_name == "stress_glass":
+        renderer.enable_transmission(True)
     renderer.upload_scene(scene)
     sr = ShardedRenderer(renderer, device)
 
@@ -272,8 +280,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "%s: %s scene (%d spheres, %d triangles in %d meshes), %dx%d, %d frames x 1 spp per GPU per step, "
-                        "max depth %d, bench pose" % (args.workload, scene_name, scene.n_spheres, scene.n_triangles,
-                                                      scene.n_meshes, width, height, frames, max_bounce),
+                        "max depth %d, bench pose%s" % (args.workload, scene_name, scene.n_spheres, scene.n_triangles,
+                                                      scene.n_meshes, width, height, frames, max_bounce,
+                                                      "; EXTENSION: every fourth sphere and mesh strip transmits (ior 1.5), no counterpart in "
+                                                      "the reference, no parity target" if scene_name == "stress_glass" else ""),
             "closest_hit": "hierarchy" if renderer.acceleration() == R.abi.ACCEL_BVH else "exhaustive loops",
             "variant": {0: "megakernel", 1: "regenerate", 2: "compact", 4: "stream"}[args.variant],
             "arithmetic_profile": renderer.profile(),

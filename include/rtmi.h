@@ -238,6 +238,17 @@ RTMI_API int rtmi_get_acceleration(const rtmi_ctx *ctx);
 #define RTMI_GRAZING_CAP_DEFAULT 0.001953125f   /* 2^-9 */
 RTMI_API int rtmi_set_grazing_cap(rtmi_ctx *ctx, float cap);
 RTMI_API float rtmi_get_grazing_cap(const rtmi_ctx *ctx);
+/* EXTENSION without a counterpart in the reference, off by default; applies to the NEXT rtmi_upload_scene.
+ * The reference's Material (RT.comp:26-34, RayTracingStructs.h:24-32) has colour, emission and smoothness; its
+ * three padding words are never read.  With this switched on, a material whose pad1 is above 0.5 transmits, with
+ * pad2 as its index of refraction: a ray that hits it is mirrored with Schlick's reflectance as probability and
+ * refracted into the object otherwise (every hit that RaySphere / RayTriangle report is from outside, so the ray
+ * always enters; the tests see no inside, so it then leaves unseen).  The branch draws the same three random
+ * numbers as the diffuse / specular one, so all other paths of an image keep their random streams.  There is no
+ * parity target for it: the kernels agree bit for bit with the CPU oracle's statement of the same rule, nothing
+ * more.  Scenes with such a material are rendered by the REGENERATE and STREAM kernels (COMPACT falls back).
+ * Switched off, the padding is ignored whatever it holds. */
+RTMI_API int rtmi_enable_transmission(rtmi_ctx *ctx, int on);
 /* Profile for the NEXT rtmi_upload_scene (default RTMI_PROFILE_STRICT): the upload precomputes each
  * triangle's AB x AC in the profile's arithmetic, and launches use the kernels of the profile the scene
  * was uploaded under.  rtmi_get_profile tells which that is (before any upload: the mode set).  The

@@ -511,6 +511,11 @@ void orc_env_light(const orc_frame_data *fd, const float d[3], float rgb[3])
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 
+/* The transmitting-material extension (no counterpart in the shader) is applied only when switched on; off, the
+ * padding words of a material are ignored as the shader ignores them. */
+static int g_transmission = 0;
+void orc_set_transmission(int on) { g_transmission = on != 0; }
+
 /* Raytracing.comp:408-439 */
 static v3 trace(const orc_frame_data *fd, v3 o, v3 d, uint32_t *rng,
                 const orc_sphere *spheres, const orc_triangle *tris, const orc_mesh *meshes,
@@ -528,10 +533,34 @@ static v3 trace(const orc_frame_data *fd, v3 o, v3 d, uint32_t *rng,
             cn->c[ORC_N_HIT_BOUNCES]++;
             if (h.prim < fd->sphere_count) cn->c[ORC_N_SPHERE_WINS]++;
             else cn->c[ORC_N_TRI_WINS]++;
-            v3 diffuse = sh_normalize(v3_add(h.nrm, rng_direction(rng)));
-            v3 spec = sh_reflect(d, h.nrm);
-            o = h.pos;
-            d = sh_mix(diffuse, spec, h.mat.smoothness);
+            v3 rd = rng_direction(rng);
+            if (g_transmission && h.mat.pad[0] > 0.5f) {
+                /* EXTENSION, no counterpart in Raytracing.comp (its Material, :26-34, has colour, emission and
+                 * smoothness only): a transmitting material, flagged by the first padding word, index of refraction
+                 * in the second.  Every hit the shader's tests report is from outside (near sphere root only,
+                 * :146-148; triangles front-facing only, :293-294), so the ray always ENTERS: it is mirrored with
+                 * Schlick's reflectance as probability (the coin is the first of the three random numbers the
+                 * branch draws anyway, so the stream stays in step with the other materials) and refracted
+                 * otherwise; the refracted ray then leaves the object unseen, as the tests see no inside. */
+                float ior = h.mat.pad[1];
+                v3 dn = sh_normalize(d);
+                float cosi = g_clamp(-sh_dot(dn, h.nrm), 0.0f, 1.0f);
+                float eta = 1.0f / ior;
+                float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+                float r0 = (1.0f - ior) / (1.0f + ior);
+                r0 = r0 * r0;
+                float x = 1.0f - cosi;
+                float x2 = x * x;
+                float refl = r0 + (1.0f - r0) * ((x2 * x2) * x);
+                o = h.pos;
+                if (k < 0.0f || rd.x < refl * 2.0f - 1.0f) d = sh_reflect(dn, h.nrm);
+                else d = sh_along(v3_scale(dn, eta), h.nrm, eta * cosi - sqrtf(k));
+            } else {
+                v3 diffuse = sh_normalize(v3_add(h.nrm, rd));
+                v3 spec = sh_reflect(d, h.nrm);
+                o = h.pos;
+                d = sh_mix(diffuse, spec, h.mat.smoothness);
+            }
             float e = 1.0f * h.mat.light;
             light = sh_add_mul(light, v3_make(e, e, e), thr);
             thr = v3_mul(thr, v3_from(h.mat.color));

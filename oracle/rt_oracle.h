@@ -100,6 +100,9 @@ void orc_closest_hit(uint32_t sphere_count, uint32_t mesh_count,
 
 /* Sky: Raytracing.comp:390-406 */
 void  orc_env_light(const orc_frame_data *fd, const float d[3], float rgb[3]);
+/* Extension without counterpart in the shader (off by default): materials with pad[0] > 0.5 transmit, pad[1] is
+ * the index of refraction.  Process-wide switch. */
+void  orc_set_transmission(int on);
 float orc_pow(float x, float y);
 float orc_log2(float x);
 float orc_exp2(float x);

@@ -114,6 +114,7 @@ PROTOTYPES = {
     "rtmi_set_acceleration": (C.c_int, [_ctx, C.c_int]),
     "rtmi_get_acceleration": (C.c_int, [_ctx]),
     "rtmi_bvh_node_bytes": (C.c_int, []),
+    "rtmi_enable_transmission": (C.c_int, [_ctx, C.c_int]),
     "rtmi_set_grazing_cap": (C.c_int, [_ctx, C.c_float]),
     "rtmi_get_grazing_cap": (C.c_float, [_ctx]),
     "rtmi_set_profile": (C.c_int, [_ctx, C.c_int]),

@@ -65,7 +65,7 @@ void triangle_edges(const rtmi_triangle &t, bool fused, float ab[3], float ac[3]
 // the same single operations the shader would repeat per ray (Raytracing.comp:141, 288-290), so the bits the
 // kernels consume are the bits the shader would have produced.
 int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris, uint32_t nT, const rtmi_mesh *meshes,
-              uint32_t nM, bool want_bvh, bool fused, PackedScene &out, std::string &err)
+              uint32_t nM, bool want_bvh, bool fused, PackedScene &out, std::string &err, bool transmission)
 {
     out = PackedScene();
     const size_t off_sph = 0;
@@ -252,6 +252,13 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
         float *d = mat + 8 * (size_t)row;
         d[0] = m.color[0]; d[1] = m.color[1]; d[2] = m.color[2]; d[3] = m.light;
         d[4] = m.smoothness;
+        // the transmitting-material extension, when the caller has switched it on: flag and index of
+        // refraction travel in the record's padding, which the shader never reads (and a host may leave unset)
+        if (transmission && m.pad1 > 0.5f) {
+            d[5] = m.pad1;
+            d[6] = m.pad2;
+            out.has_glass = true;
+        }
     };
     for (uint32_t i = 0; i < nS; i++) {
         const rtmi_sphere &s = spheres[i];

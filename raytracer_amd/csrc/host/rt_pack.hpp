@@ -27,13 +27,16 @@ struct PackedScene {
     uint32_t node_count = 0;
     uint32_t graze_first = 0;  // node index of entry 0 of the graze records
     uint32_t n_spheres = 0, n_triangles = 0, n_meshes = 0;
+    bool has_glass = false;  // some material has its transmission flag (first padding word) set
 };
 
 // Repack the records; with want_bvh also build one hierarchy over the spheres and one per mesh.  fused picks
-// the arithmetic of AB x AC (the fused profile rounds it once per component).  Returns 0 or a negative
-// rtmi_status with the reason in err.
+// the arithmetic of AB x AC (the fused profile rounds it once per component).  transmission: read the first two
+// padding words of every material as transmission flag and index of refraction (rtmi_enable_transmission);
+// otherwise the padding is ignored, as the shader ignores it.  Returns 0 or a negative rtmi_status with the
+// reason in err.
 int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris, uint32_t nT, const rtmi_mesh *meshes,
-              uint32_t nM, bool want_bvh, bool fused, PackedScene &out, std::string &err);
+              uint32_t nM, bool want_bvh, bool fused, PackedScene &out, std::string &err, bool transmission = false);
 
 }  // namespace rtmi
 
@@ -65,6 +68,7 @@ int PackScene(const rtmi_sphere *spheres, uint32_t nS, const rtmi_triangle *tris
         (DS).bvh_mesh_info = (PK).bvh ? reinterpret_cast<const uint4 *>(b_ + (PK).off_mroot) : nullptr;                    \
         (DS).bvh_sphere_root = (PK).sphere_root;                                                                           \
         (DS).bvh_node_count = (PK).bvh ? (PK).node_count : 0u;                                                             \
+        (DS).has_glass = (PK).has_glass ? 1u : 0u;                                                                         \
         (DS).bvh_graze = (PK).bvh ? reinterpret_cast<const uint4 *>(b_ + (PK).off_graze) : nullptr;                        \
         (DS).bvh_graze_first = (PK).graze_first;                                                                           \
     } while (0)

@@ -294,6 +294,7 @@ struct DeviceScene {
     const uint4 *bvh_graze;
     uint32_t bvh_graze_first;
     float bvh_graze_cap;            // largest margin, as a fraction of the distance, that such a ray is given
+    uint32_t has_glass;             // some material transmits (the extension in bounce<GLASS>)
 };
 
 // Fetch of a record whose index is the same in every lane.  The scene arrays are never written by a
@@ -719,20 +720,47 @@ __device__ __forceinline__ V3 env_light_wave(const Sky &sky, V3 d, bool want, ui
 }
 
 // The hit branch of Trace, Raytracing.comp:417-431.
+//
+// GLASS (an extension without counterpart in the shader, whose Material, Raytracing.comp:26-34, has colour,
+// emission and smoothness only): a material whose first padding word is above 0.5 transmits, with the index of
+// refraction in its second padding word.  Every hit the shader's tests report is from outside (near sphere root
+// only, :146-148; front-facing triangles only, :293-294), so the ray always enters: mirrored with Schlick's
+// reflectance as probability (the coin is the first of the three random numbers the branch draws anyway),
+// refracted otherwise.  Scenes without such a material run the instantiations without this code.
+template <bool GLASS = false>
 __device__ __forceinline__ void bounce(const DeviceScene &sc, uint32_t n_spheres, const Hit &h,
                                        V3 &o, V3 &d, V3 &light, V3 &thr, uint32_t &rng)
 {
     V3 pos, nrm;
     resolve_hit(sc, n_spheres, o, d, h, pos, nrm);
     const float4 m0 = sc.materials[2 * h.mat + 0];
-    const float smooth = sc.materials[2 * h.mat + 1].x;
+    const float4 m1 = sc.materials[2 * h.mat + 1];   // {smoothness, transmission flag, index of refraction, 0}
+    const float smooth = m1.x;
     float rx = twice_minus_one(rng_next(rng));
     float ry = twice_minus_one(rng_next(rng));
     float rz = twice_minus_one(rng_next(rng));
-    V3 diffuse = normalize(nrm + mk(rx, ry, rz));
-    V3 spec = reflect(d, nrm);
-    o = pos;
-    d = gmix(diffuse, spec, smooth);
+    bool transmits = false;
+    if constexpr (GLASS) transmits = m1.y > 0.5f;
+    if (transmits) {
+        const float ior = m1.z;
+        const V3 dn = normalize(d);
+        const float cosi = gclamp(-dot(dn, nrm), 0.0f, 1.0f);
+        const float eta = 1.0f / ior;
+        const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+        float r0 = (1.0f - ior) / (1.0f + ior);
+        r0 = r0 * r0;
+        const float x = 1.0f - cosi;
+        const float x2 = x * x;
+        const float refl = r0 + (1.0f - r0) * ((x2 * x2) * x);
+        o = pos;
+        if (k < 0.0f || rx < twice_minus_one(refl)) d = reflect(dn, nrm);
+        else d = along(dn * eta, nrm, eta * cosi - sqrtf(k));
+    } else {
+        V3 diffuse = normalize(nrm + mk(rx, ry, rz));
+        V3 spec = reflect(d, nrm);
+        o = pos;
+        d = gmix(diffuse, spec, smooth);
+    }
     float e = 1.0f * m0.w;
     light = add_mul(light, mk(e, e, e), thr);
     thr = thr * mk(m0.x, m0.y, m0.z);

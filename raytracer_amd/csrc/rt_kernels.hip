@@ -199,7 +199,7 @@ __device__ __forceinline__ V3 load_sum(const RenderParams &p, uint32_t x, uint32
 // --------------------------------------------------------------------------------------------
 // Variant 0: loops nested exactly as the shader nests them.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE, bool BVH>
+template <bool VALIDATE, bool BVH, bool GLASS = false>
 __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams p)
 {
     RT_BVH_STACK(kBlockThreads);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
                             if (h.prim < nS) cn.c[2]++;
                             else cn.c[5]++;
                         }
-                        bounce(sc, nS, h, o, d, light, thr, rng);
+                        bounce<GLASS>(sc, nS, h, o, d, light, thr, rng);
                     } else {
                         if (VALIDATE) cn.c[7]++;
                         light = add_mul(light, env_light(sky, d), thr);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_megakernel(const RenderParams
 // --------------------------------------------------------------------------------------------
 // Variant 1: one loop over segments; lanes regenerate their own next path.
 // --------------------------------------------------------------------------------------------
-template <bool VALIDATE, bool BVH, bool STORE = false>
+template <bool VALIDATE, bool BVH, bool STORE = false, bool GLASS = false>
 __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams p)
 {
     RT_BVH_STACK(kBlockThreads);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_regenerate(const RenderParams
                 p.primary[px] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
                 p.primary_mat[px] = h.mat;
             }
-            bounce(sc, nS, h, o, d, light, thr, rng);
+            bounce<GLASS>(sc, nS, h, o, d, light, thr, rng);
             i++;
             path_done = i >= p.max_bounce;
         } else {
@@ -376,7 +376,7 @@ constexpr uint32_t kStreamLargeSceneNodes = (4u << 20) / 32u;
 
 // RPP1: the launch has one sample per pixel and frame (the launcher checks): a finished path is a finished frame,
 // and no sample counter or partial frame sum is carried.
-template <bool VALIDATE, bool RPP1 = false, int WAVES = RT_STREAM_MIN_WAVES>
+template <bool VALIDATE, bool RPP1 = false, int WAVES = RT_STREAM_MIN_WAVES, bool GLASS = false>
 __global__ __launch_bounds__(kStreamThreads, WAVES) void k_stream(const RenderParams p)
 {
     constexpr bool BVH = true;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kStreamThreads, WAVES) void k_stream(const RenderPa
                     if (h.prim < nS) cn.c[2]++;
                     else cn.c[5]++;
                 }
-                bounce(sc, nS, h, o, d, light, thr, rng);
+                bounce<GLASS>(sc, nS, h, o, d, light, thr, rng);
                 i++;
                 path_done = i >= p.max_bounce;
             } else {
@@ -1000,6 +1000,29 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
         else if (bvh) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, stream, p);               \
         else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, stream, p);                       \
     } while (0)
+    // Scenes with a transmitting material (an extension, rt_device.hpp bounce<GLASS>): the nested, the regenerating
+    // and the streaming kernel have an instantiation for it; the compacting pair and the launches that start from
+    // stored primary hits keep the shader's two-lobe material in their start records and are not used.
+    const bool glass = p.scene.has_glass != 0u;
+    if (glass) {
+        if (cache != RT_CACHE_NONE) return hipErrorInvalidValue;
+        if (variant == 2) variant = 1;
+        if ((variant == 1 || variant == 4) && (p.max_bounce == 0 || p.rays_per_pixel == 0)) variant = 0;
+        if (variant == 0) {
+            if (validate && bvh) hipLaunchKernelGGL((k_megakernel<true, true, true>), grid, block, 0, stream, p);
+            else if (validate) hipLaunchKernelGGL((k_megakernel<true, false, true>), grid, block, 0, stream, p);
+            else if (bvh) hipLaunchKernelGGL((k_megakernel<false, true, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_megakernel<false, false, true>), grid, block, 0, stream, p);
+            return hipGetLastError();
+        }
+        if (variant == 1) {
+            if (validate && bvh) hipLaunchKernelGGL((k_regenerate<true, true, false, true>), grid, block, 0, stream, p);
+            else if (validate) hipLaunchKernelGGL((k_regenerate<true, false, false, true>), grid, block, 0, stream, p);
+            else if (bvh) hipLaunchKernelGGL((k_regenerate<false, true, false, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_regenerate<false, false, false, true>), grid, block, 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (variant == 0) {
         RT_LAUNCH(k_megakernel, grid, block);
     } else if (variant == 1) {
@@ -1080,7 +1103,10 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
 #else
         const bool one_sample = p.rays_per_pixel == 1u;
 #endif
-        if (validate && one_sample) hipLaunchKernelGGL((k_stream<true, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        if (glass && validate) hipLaunchKernelGGL((k_stream<true, false, RT_STREAM_MIN_WAVES, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (glass && large) hipLaunchKernelGGL((k_stream<false, false, RT_STREAM_MIN_WAVES_LARGE, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (glass) hipLaunchKernelGGL((k_stream<false, false, RT_STREAM_MIN_WAVES, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
+        else if (validate && one_sample) hipLaunchKernelGGL((k_stream<true, true>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
         else if (validate) hipLaunchKernelGGL((k_stream<true, false>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);
         else if (large && one_sample)
             hipLaunchKernelGGL((k_stream<false, true, RT_STREAM_MIN_WAVES_LARGE>), grid_stream, dim3(kStreamThreads, 1, 1), 0, stream, p);

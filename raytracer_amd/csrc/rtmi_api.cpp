@@ -77,6 +77,7 @@ struct rtmi_ctx {
     rtd::DeviceScene dscene{};
     int accel_mode = RTMI_ACCEL_AUTO;  // applied by the next rtmi_upload_scene
     float graze_cap = RTMI_GRAZING_CAP_DEFAULT;  // rtmi_set_grazing_cap
+    bool transmission = false;         // rtmi_enable_transmission: applied by the next rtmi_upload_scene
     bool bvh_active = false;           // the uploaded scene carries hierarchies and the kernels use them
     int profile_mode = RTMI_PROFILE_STRICT;  // applied by the next rtmi_upload_scene
     bool fused = false;                // the uploaded scene was prepared for, and is rendered by, the fused profile
@@ -281,7 +282,7 @@ int rtmi_upload_scene(rtmi_ctx *c, const rtmi_sphere *spheres, uint32_t nS, cons
     // everything up to the bytes that go to the device is host work (host/rt_pack.cpp)
     rtmi::PackedScene pk;
     std::string why;
-    if (const int rc = rtmi::PackScene(spheres, nS, tris, nT, meshes, nM, want_bvh, fused, pk, why)) return fail(c, rc, "%s", why.c_str());
+    if (const int rc = rtmi::PackScene(spheres, nS, tris, nT, meshes, nM, want_bvh, fused, pk, why, c->transmission)) return fail(c, rc, "%s", why.c_str());
     const size_t total = pk.blob.size();
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -405,8 +406,11 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // scene at 1080p: 1 frame 11.4 ms against COMPACT's 27, 8 frames 80 against 93, 16 frames 158 against
         // 172, 64 frames 630 against 643); it starts from nothing stored.
         const bool stream = c->bvh_active;
-        const bool use_store = compact_runs && !c->validate && !stream && !no_alloc;
-        const bool compact = !stream && paths_per_pixel >= 8u;
+        // a scene with transmitting materials (the extension) is rendered by the one-lane-per-pixel and the
+        // streaming kernels only, and starts from nothing stored
+        const bool glass = c->dscene.has_glass != 0u;
+        const bool use_store = compact_runs && !c->validate && !stream && !no_alloc && !glass;
+        const bool compact = !stream && paths_per_pixel >= 8u && !glass;
         if (use_store) {
             const size_t np = n_pixels(c);
             if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
@@ -539,6 +543,13 @@ int rtmi_set_grazing_cap(rtmi_ctx *c, float cap)
 }
 
 float rtmi_get_grazing_cap(const rtmi_ctx *c) { return c ? c->graze_cap : -1.0f; }
+
+int rtmi_enable_transmission(rtmi_ctx *c, int on)
+{
+    if (!c) return RTMI_ERR_INVALID_ARGUMENT;
+    c->transmission = on != 0;
+    return RTMI_OK;
+}
 
 int rtmi_get_acceleration(const rtmi_ctx *c) { return c ? (c->bvh_active ? RTMI_ACCEL_BVH : RTMI_ACCEL_NONE) : RTMI_ERR_INVALID_ARGUMENT; }
 

@@ -262,6 +262,11 @@ class Renderer:
         """abi.ACCEL_AUTO / ACCEL_NONE / ACCEL_BVH for the next upload_scene."""
         self._check(self._lib.rtmi_set_acceleration(self._ctx, mode))
 
+    def enable_transmission(self, on=True):
+        """The transmitting-material extension (rtmi_enable_transmission) for the next upload_scene: materials
+        whose pad[0] is above 0.5 refract, pad[1] is the index of refraction."""
+        self._check(self._lib.rtmi_enable_transmission(self._ctx, 1 if on else 0))
+
     def set_grazing_cap(self, cap):
         """Largest extra margin (fraction of the distance) the boxes of a mesh of small triangles are given for
         a ray that runs almost inside a triangle's plane (rtmi_set_grazing_cap); 0 = none, 1.0 = the proven

@@ -10,11 +10,15 @@ from . import host
 
 
 def stress_scene(n_spheres=1_000_000, grid=(1000, 500), n_meshes=16, seed=12345, extent=50.0,
-                 radius_range=(0.05, 0.25)):
+                 radius_range=(0.05, 0.25), glass=False):
     """n_spheres spheres with centres uniform in [-extent, extent]^3 and radii uniform in
     radius_range, plus a displaced grid of grid[0] x grid[1] cells (two triangles each) spanning the
     same square at about y = -0.3 extent, cut into n_meshes strips with one Mesh record each.
     Materials cycle diffuse / mirror / half-smooth; one sphere in 61 emits light.
+    glass=True (an extension: the reference has no transmitting material, Raytracing.comp:26-34) makes every fourth
+    sphere and every fourth mesh strip transmit with an index of refraction of 1.5; it takes effect only on a
+    renderer with the transmission extension enabled, and draws nothing from the random stream, so the
+    geometry and the other materials are those of the plain scene.
     Returns (Scene, pose) where pose looks into the cube from outside its -z face."""
     rs = np.random.RandomState(seed)
     e = float(extent)
@@ -26,6 +30,9 @@ def stress_scene(n_spheres=1_000_000, grid=(1000, 500), n_meshes=16, seed=12345,
     sph["material"]["color"] = rs.uniform(0.2, 1.0, size=(n_spheres, 3)).astype(np.float32)
     sph["material"]["smoothness"] = np.choose(idx % 3, [0.0, 1.0, 0.5]).astype(np.float32)
     sph["material"]["light"] = np.where(idx % 61 == 7, 2.0, 0.0).astype(np.float32)
+    if glass:
+        sph["material"]["pad"][:, 0] = np.where(idx % 4 == 3, 1.0, 0.0).astype(np.float32)
+        sph["material"]["pad"][:, 1] = 1.5
 
     nx, nz = int(grid[0]), int(grid[1])
     if nx * nz == 0 or n_meshes == 0:
@@ -69,6 +76,9 @@ def stress_scene(n_spheres=1_000_000, grid=(1000, 500), n_meshes=16, seed=12345,
         meshes["bounding_point2"][m, :3] = verts.max(axis=0)
         meshes["material"]["color"][m] = rs.uniform(0.3, 0.9, size=3).astype(np.float32)
         meshes["material"]["smoothness"][m] = (0.0, 1.0, 0.5)[m % 3]
+        if glass and m % 4 == 3:
+            meshes["material"]["pad"][m, 0] = 1.0
+            meshes["material"]["pad"][m, 1] = 1.5
     return host.Scene.from_records(sph, tri.reshape(-1), meshes), _pose(e)
 
 

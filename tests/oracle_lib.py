@@ -91,6 +91,8 @@ def lib(profile=None):
     L.orc_ray_triangle.argtypes = [f3, f3, C.POINTER(Triangle), f3, f3, f3]
     L.orc_ray_box.restype = C.c_int
     L.orc_ray_box.argtypes = [f3, f3, f3, f3]
+    L.orc_set_transmission.restype = None
+    L.orc_set_transmission.argtypes = [C.c_int]
     L.orc_env_light.restype = None
     L.orc_env_light.argtypes = [C.POINTER(FrameData), f3, f3]
     for name in ("orc_log2", "orc_exp2"):

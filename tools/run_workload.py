@@ -8,7 +8,8 @@ import raytracer_amd as R
 
 WORKLOADS = {"c2_spheres": ("spheres", 1920, 1080, 8), "c3_mesh": ("reference", 1920, 1080, 8),
              "c4_mesh_4k": ("reference", 3840, 2160, 8), "c1_plumbing": ("reference", 640, 360, 4),
-             "c5_stress": ("stress", 1920, 1080, 16), "c5_small": ("stress_small", 1920, 1080, 16)}
+             "c5_stress": ("stress", 1920, 1080, 16), "c5_small": ("stress_small", 1920, 1080, 16),
+             "c5_stress_glass": ("stress_glass", 1920, 1080, 16)}
 name = sys.argv[1] if len(sys.argv) > 1 else "c2_spheres"
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -19,6 +20,8 @@ pose = R.BENCH_POSE
 t0 = time.perf_counter()
 if scene_name == "stress":
     scene, pose = R.scenes.stress_scene()
+elif scene_name == "stress_glass":
+    scene, pose = R.scenes.stress_scene(glass=True)
 elif scene_name == "stress_small":
     scene, pose = R.scenes.stress_scene(5000, (50, 50), 4, extent=5.0)
 else:
@@ -27,6 +30,8 @@ t_gen = time.perf_counter() - t0
 fd = R.make_frame_data(w, h, scene, pose, 1, mb)
 with R.Renderer(w, h, variant=variant) as r:
     r.set_acceleration(accel)
+    if scene_name == "stress_glass":
+        r.enable_transmission(True)
     t0 = time.perf_counter()
     r.upload_scene(scene)
     t_up = time.perf_counter() - t0
