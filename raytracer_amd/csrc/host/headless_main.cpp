@@ -30,6 +30,7 @@ struct Options {
     int device = 0;
     int gpus = 0;  // > 0: frames split over GPUs 0 .. gpus-1 of this node, images summed with RCCL (implies --batch)
     int quad_rule = 0;
+    bool transmission = false;   // the transmitting-material extension (rtmi_enable_transmission)
     int profile = RTMI_PROFILE_STRICT;  // arithmetic profile (--profile, default from the environment variable RTMI_PROFILE)
 };
 
@@ -37,7 +38,7 @@ void Usage()
 {
     std::puts("rtmi_headless [--size W H] [--frames N] [--rpp N] [--bounces N] [--pose x y z yaw pitch]\n"
               "              [--meshes DIR] [--ppm FILE] [--pfm FILE] [--exr FILE] [--variant 0|1|2|3|4] [--batch]\n"
-              "              [--move-at FRAME] [--device N] [--fan] [--profile strict|fma]\n"
+              "              [--move-at FRAME] [--device N] [--fan] [--profile strict|fma] [--transmission]\n"
               "              [--gpus N]           static camera: frames 1..N split over GPUs 0..N-1, one RCCL sum at the end\n"
               "              [--scene FILE]       text scene file instead of the built-in scene\n"
               "              [--script FILE]      camera input, one line per run of frames:\n"
@@ -128,6 +129,7 @@ int main(int argc, char **argv)
         else if (a == "--device" && need(1)) o.device = std::atoi(argv[++i]);
         else if (a == "--gpus" && need(1)) { o.gpus = std::atoi(argv[++i]); o.batch = true; }
         else if (a == "--fan") o.quad_rule = 1;
+        else if (a == "--transmission") o.transmission = true;
         else if (a == "--profile" && need(1)) { if (!profile_by_name(argv[++i], o.profile)) { Usage(); return 2; } }
         else if (a == "--scene" && need(1)) o.scene = argv[++i];
         else if (a == "--script" && need(1)) o.script = argv[++i];
@@ -205,6 +207,7 @@ int main(int argc, char **argv)
                 group[(size_t)g] = c;
                 if (!Check(c, rtmi_set_variant(c, o.variant), "rtmi_set_variant")) return;
                 if (!Check(c, rtmi_set_profile(c, o.profile), "rtmi_set_profile")) return;
+                if (!Check(c, rtmi_enable_transmission(c, o.transmission ? 1 : 0), "rtmi_enable_transmission")) return;
                 if (!Check(c, rtmi_upload_scene(c, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
                            "rtmi_upload_scene"))
                     return;
@@ -222,6 +225,7 @@ int main(int argc, char **argv)
         if (!Check(nullptr, rtmi_create(o.device, o.width, o.height, &ctx), "rtmi_create")) return 1;
         if (!Check(ctx, rtmi_set_variant(ctx, o.variant), "rtmi_set_variant")) return 1;
         if (!Check(ctx, rtmi_set_profile(ctx, o.profile), "rtmi_set_profile")) return 1;
+        if (!Check(ctx, rtmi_enable_transmission(ctx, o.transmission ? 1 : 0), "rtmi_enable_transmission")) return 1;
         if (!Check(ctx, rtmi_upload_scene(ctx, spheres.data(), (uint32_t)spheres.size(), tris.data(), nT, meshes.data(), nM),
                    "rtmi_upload_scene"))
             return 1;

@@ -40,6 +40,11 @@ void PutMaterial(FILE *f, const Material &m)
     PutFloats(f, m.color, 3);
     PutFloats(f, &m.light, 1);
     PutFloats(f, &m.smoothness, 1);
+    // the transmitting-material extension: flag and index of refraction, written only when set
+    if (m.pad1 != 0.0f || m.pad2 != 0.0f) {
+        PutFloats(f, &m.pad1, 1);
+        PutFloats(f, &m.pad2, 1);
+    }
 }
 
 // reads n floats from *p, advancing it; false if fewer are there
@@ -59,7 +64,12 @@ bool GetFloats(char *&p, float *v, int n)
 bool GetMaterial(char *&p, Material &m)
 {
     std::memset(&m, 0, sizeof m);
-    return GetFloats(p, m.color, 3) && GetFloats(p, &m.light, 1) && GetFloats(p, &m.smoothness, 1);
+    if (!GetFloats(p, m.color, 3) || !GetFloats(p, &m.light, 1) || !GetFloats(p, &m.smoothness, 1)) return false;
+    // optionally the two words of the transmitting-material extension (both or neither)
+    const char *q = p;
+    while (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\n') q++;
+    if (*q == '\0') return true;
+    return GetFloats(p, &m.pad1, 1) && GetFloats(p, &m.pad2, 1);
 }
 
 bool OnlySpaceLeft(const char *p)
@@ -76,7 +86,7 @@ bool SaveScene(const char *path, const Scene &scene)
 {
     File out(path, "w");
     if (!out.f) return false;
-    std::fprintf(out.f, "rtmi-scene 1\n# sphere cx cy cz radius  r g b light smoothness\n");
+    std::fprintf(out.f, "rtmi-scene 1\n# sphere cx cy cz radius  r g b light smoothness [transmission ior]\n");
     for (const Sphere &s : scene.spheres) {
         std::fputs("sphere", out.f);
         PutFloats(out.f, s.center, 3);
@@ -91,7 +101,7 @@ bool SaveScene(const char *path, const Scene &scene)
         for (const float *q : v) PutFloats(out.f, q, 3);
         std::fputc('\n', out.f);
     }
-    std::fprintf(out.f, "# mesh start_triangle num_triangles  box_lo box_hi  r g b light smoothness\n");
+    std::fprintf(out.f, "# mesh start_triangle num_triangles  box_lo box_hi  r g b light smoothness [transmission ior]\n");
     for (const Mesh &m : scene.meshes) {
         std::fprintf(out.f, "mesh %" PRId32 " %" PRId32, m.start_triangle, m.num_triangles);
         PutFloats(out.f, m.bounding_point1, 3);

@@ -266,6 +266,11 @@ def test_scene_file_round_trip_is_bit_exact(rtmi, tmp_path):
     back = rtmi.Scene.load(path)
     assert (back.n_spheres, back.n_triangles, back.n_meshes) == (200, 60, 3)
     assert _records(back, rtmi) == _records(sc, rtmi)
+    # materials of the transmitting-material extension keep their two extra words
+    glass, _ = rtmi.scenes.stress_scene(40, (4, 4), 4, seed=5, extent=3.0, glass=True)
+    glass.save(path)
+    assert _records(rtmi.Scene.load(path), rtmi) == _records(glass, rtmi)
+    assert "1.5" in path.read_text()
     # the reference scene too, and an empty scene
     ref = rtmi.reference_scene()
     ref.save(path)
