@@ -75,6 +75,10 @@ def test_bench_starts_its_own_ranks_rehearsal():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0
     assert res["config"]["total_frames"] == 2 * res["config"]["frames_per_gpu"]
+    # what makes a scaling loss attributable: per-step time of the collective and the render kernels over the ranks
+    assert res["reduce_ms"]["max_over_ranks"] >= res["reduce_ms"]["min_over_ranks"] >= 0.0
+    assert res["kernel_ms_over_ranks"]["max"] >= res["kernel_ms_over_ranks"]["min"] > 0.0
+    assert res["reduce_payload_bytes"] == 640 * 360 * 16
 
 
 def test_bench_refuses_more_gpus_than_there_are():
