@@ -145,6 +145,9 @@ def main():
                          "headline number is quoted in) or fma (fused multiply-adds at a fixed list of sites)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1: one context per rank, every step's collective finishes before the next step's render starts "
+                         "(default: two contexts take alternate steps, so the collective overlaps the next render)")
     ap.add_argument("--reduce", default="reduce", choices=["reduce", "allreduce"],
                     help="N > 1: sum the images onto rank 0 only (default; the only rank that resolves and would "
                          "dump the picture) or onto every rank")
@@ -185,18 +188,32 @@ def main():
     fd = R.make_frame_data(width, height, scene, pose, rays_per_pixel=1, max_bounce=max_bounce)
     total_frames = frames * world
 
-    renderer = R.Renderer(width, height, device=local_rank, variant=args.variant, profile=args.profile)
-    if scene_name == "stress_glass":
-        renderer.enable_transmission(True)
-    renderer.upload_scene(scene)
+    def make_renderer():
+        r = R.Renderer(width, height, device=local_rank, variant=args.variant, profile=args.profile)
+        if scene_name == "stress_glass":
+            r.enable_transmission(True)
+        r.upload_scene(scene)
+        return r
+
+    renderer = make_renderer()
     sr = ShardedRenderer(renderer, device)
+    # N > 1: consecutive steps (images) alternate between two contexts, each with an accumulation image and a
+    # stream of its own, so that the sum of one image over the ranks runs while the next image is being rendered
+    # (what a host producing a sequence of images would do); every step is still a full render of this rank's
+    # frames plus the collective plus, on the rank holding the sum, the resolve.  --no-pipeline keeps one context.
+    pipelined = world > 1 and not args.no_pipeline
+    renderers = [renderer, make_renderer()] if pipelined else [renderer]
+    srs = [sr, ShardedRenderer(renderers[1], device)] if pipelined else [sr]
+    step_no = [0]
 
     dst = 0 if args.reduce == "reduce" else None
 
     def step():
-        sr.render(fd, total_frames, dst=dst)
+        s = srs[step_no[0] % len(srs)]
+        step_no[0] += 1
+        s.render(fd, total_frames, dst=dst, join=not pipelined)
         if world > 1 and (dst is None or rank == dst):
-            sr.resolve(total_frames)
+            s.resolve(total_frames, join=not pipelined)
 
     # algorithmic work of this rank's launch, from exact event counters (instrumented kernel, untimed)
     first = 1 + rank * frames
@@ -227,9 +244,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
-    renderer.timing_reset(True)
+    for r_ in renderers:
+        r_.timing_reset(True)
     if world > 1:
-        sr.time_collectives(True)
+        for s_ in srs:
+            s_.time_collectives(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -238,12 +257,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = renderer.timing_read()
-    renderer.timing_reset(False)
+    kernel_ms_total, launches = 0.0, 0
+    for r_ in renderers:
+        ms_, n_ = r_.timing_read()
+        kernel_ms_total += ms_
+        launches += n_
+        r_.timing_reset(False)
     reduce_ms = kernel_ms_max = kernel_ms_min = None
     if world > 1:
-        coll_ms_total, n_coll = sr.collective_ms()
-        sr.time_collectives(False)
+        coll_ms_total, n_coll = 0.0, 0
+        for s_ in srs:
+            ms_, n_ = s_.collective_ms()
+            coll_ms_total += ms_
+            n_coll += n_
+            s_.time_collectives(False)
         # per rank: wall seconds, render-kernel ms per step, collective ms per step (transfer + wait for slower ranks)
         mine = torch.tensor([elapsed, kernel_ms_total / max(1, launches), coll_ms_total / max(1, n_coll)],
                             dtype=torch.float64, device=device)
@@ -288,8 +315,10 @@ def main():
             "variant": {0: "megakernel", 1: "regenerate", 2: "compact", 4: "stream"}[args.variant],
             "arithmetic_profile": renderer.profile(),
             "frames_per_gpu": frames, "total_frames": total_frames,
-            "parallelism": "frame-range split x%d + RCCL %s(sum) of float4 accumulation" % (
-                world, "reduce to rank 0" if dst is not None else "all-reduce") if world > 1 else "single GPU",
+            "parallelism": "frame-range split x%d + RCCL %s(sum) of float4 accumulation%s" % (
+                world, "reduce to rank 0" if dst is not None else "all-reduce",
+                "; consecutive steps alternate between two contexts so that a step's collective overlaps the next step's render"
+                if pipelined else "") if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "fp32_valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -364,7 +393,9 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     sr = None
-    renderer.close()
+    srs = None
+    for r_ in renderers:
+        r_.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -42,6 +42,12 @@ def render_sharded(render_range, accum, total_frames, first_frame=1, group=None,
     if n > 0:
         render_range(first, n)
     if world > 1:
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo (the CPU tests' backend, and the one-GPU rehearsal of the multi-GPU bench) stages device
+            # tensors through the host on streams of its own; started while this rank's render kernel is still
+            # running, with two processes sharing one GPU, it has been seen to stall the kernel for seconds or
+            # for good.  RCCL, the backend that matters, orders itself after the kernels on the device.
+            torch.cuda.current_stream(accum.device).synchronize()
         if around_collective is not None:
             around_collective("before")
         if dst is None:
@@ -95,8 +101,13 @@ class ShardedRenderer:
             self._collective_events = []
         return total, n
 
-    def render(self, fd, total_frames, first_frame=1, group=None, dst=None):
-        """This rank's share of the frames + the sum over ranks (all ranks, or rank dst only)."""
+    def render(self, fd, total_frames, first_frame=1, group=None, dst=None, join=True):
+        """This rank's share of the frames + the sum over ranks (all ranks, or rank dst only).
+
+        join=False leaves the caller's stream out of it at the end: the sequence stays on this object's stream
+        and the caller synchronises when it needs the image (join() below, or a device-wide wait).  That is what
+        lets two ShardedRenderers, each with a context and an image of its own, take alternate images of a
+        sequence: the collective of one image then runs while the other context renders the next."""
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         hook = None
@@ -110,15 +121,21 @@ class ShardedRenderer:
         with torch.cuda.stream(self.stream):
             rng = render_sharded(lambda first, n: self.renderer.render_frames(fd, first, n), self.accum,
                                  total_frames, first_frame, group, dst, hook)
-        caller.wait_stream(self.stream)
+        if join:
+            caller.wait_stream(self.stream)
         return rng
 
-    def resolve(self, total_frames):
+    def resolve(self, total_frames, join=True):
         """Alpha back to 1 and the display image = sum / total_frames (on the rank(s) holding the sum)."""
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         self.renderer.resolve_output(total_frames)   # launches on self.stream
-        caller.wait_stream(self.stream)
+        if join:
+            caller.wait_stream(self.stream)
+
+    def join(self):
+        """The caller's current stream waits for everything enqueued here so far (after render / resolve with join=False)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def close(self):
         """Give the renderer back its own image and stream."""

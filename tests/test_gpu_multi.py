@@ -67,18 +67,30 @@ def _bench(args, env_extra=None):
 
 def test_bench_starts_its_own_ranks_rehearsal():
     """`python bench.py --gpus 2` as the driver invokes it, with both ranks on GPU 0 over gloo."""
-    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c1_plumbing", "--no-cpu-baseline"],
+    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c1_plumbing", "--no-cpu-baseline"],
                  {"RTMI_BENCH_REHEARSE": "1"})
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0
     assert res["config"]["total_frames"] == 2 * res["config"]["frames_per_gpu"]
     # what makes a scaling loss attributable: per-step time of the collective and the render kernels over the ranks
     assert res["reduce_ms"]["max_over_ranks"] >= res["reduce_ms"]["min_over_ranks"] >= 0.0
     assert res["kernel_ms_over_ranks"]["max"] >= res["kernel_ms_over_ranks"]["min"] > 0.0
     assert res["reduce_payload_bytes"] == 640 * 360 * 16
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-pipeline"], ["--reduce", "allreduce"]])
+def test_bench_rehearsal_full_size_image(extra):
+    """The default workload's 33 MB image through the N > 1 bench path, six steps: alternating contexts (the default),
+    one context, and the all-reduce."""
+    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--frames", "32", "--no-cpu-baseline"] + extra,
+                 {"RTMI_BENCH_REHEARSE": "1"})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["reduce_payload_bytes"] == 1920 * 1080 * 16
+    assert ("alternate" in res["config"]["parallelism"]) == (extra != ["--no-pipeline"])
 
 
 def test_bench_refuses_more_gpus_than_there_are():
