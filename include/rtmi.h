@@ -129,8 +129,9 @@ typedef enum rtmi_variant {
  * what the error bound demands; boxes of small triangles are grown by the bound itself, at most by the
  * fraction of the distance set with rtmi_set_grazing_cap (default 2^-9).  With the cap at 1 the hierarchy
  * provably returns the hit of the exhaustive loops for every ray; with a smaller cap that holds for every ray
- * except those within about 2e-6 / cap radians (0.06 degrees at the default) of the plane of a small triangle
- * that they pass at more than cap times their distance from it.  Probes of several million rays aimed along
+ * except those within about 1.2e-6 G / (|n| cap) radians of the plane of a small triangle (G / |n|, a measure of
+ * its aspect ratio, is 3.5 for an equilateral triangle: 0.12 degrees at the default) that they pass at more than
+ * cap times their distance from it.  Probes of several million rays aimed along
  * triangle planes found no difference at any cap, 0 included (tools/grazing_rate.py).
  * RTMI_ACCEL_AUTO builds hierarchies when the scene holds more than 256 primitives.  The
  * reference has no counterpart (its scene holds 1 sphere and 14 triangles in 2 meshes, main.cpp:161-185). */
