@@ -76,6 +76,13 @@ def test_sharded_render_matches_single_process(oracle, tmp_path, world, total, d
         acc = np.load(tmp_path / ("accum_%d.npy" % r))
         # float sums are re-associated (per-rank partial sums, then the collective): a few ulp per frame
         assert np.allclose(acc[..., :3], ref["accum"][..., :3], rtol=0, atol=total * 4e-7 * max(1.0, ref["accum"].max()))
+        # the stated tolerance of the mean radiance at equal samples per pixel: per-pixel maximum absolute error
+        # of the mean below 1e-6 of the largest value, and PSNR (peak 1, values clamped to [0, 1]) of at least
+        # 50 dB; what a re-associated float sum of a few images does is far inside both
+        mean, want = acc[..., :3].astype(np.float64) / total, ref["accum"][..., :3].astype(np.float64) / total
+        assert np.abs(mean - want).max() <= 1e-6 * max(1.0, float(want.max()))
+        mse = float(np.mean((np.clip(mean, 0, 1) - np.clip(want, 0, 1)) ** 2))
+        assert mse == 0.0 or 10.0 * np.log10(1.0 / mse) >= 50.0
         n_rendering = sum(1 for _, n in ranges if n > 0)
         assert (acc[..., 3] == float(n_rendering)).all()
     if world == 2 and dst is None:

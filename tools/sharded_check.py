@@ -91,6 +91,14 @@ def main():
         tol = total * 4e-7 * max(1.0, float(whole.max()))
         if not np.allclose(got, whole[..., :3], rtol=0, atol=tol):
             problems.append("sum differs from the one-context render: max abs %g > %g" % (float(np.abs(got - whole[..., :3]).max()), tol))
+        # the stated tolerance at equal samples per pixel: maximum absolute error of the mean radiance and PSNR
+        # (peak 1, values clamped to [0, 1]) against the one-context render of all frames
+        m_got, m_whole = got.astype(np.float64) / total, whole[..., :3].astype(np.float64) / total
+        max_abs = float(np.abs(m_got - m_whole).max())
+        mse = float(np.mean((np.clip(m_got, 0, 1) - np.clip(m_whole, 0, 1)) ** 2))
+        psnr = float("inf") if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
+        if max_abs > 1e-6 * max(1.0, float(m_whole.max())) or psnr < 50.0:
+            problems.append("mean radiance: max abs error %g, PSNR %.1f dB" % (max_abs, psnr))
         if not (summed[..., 3] == 1.0).all():
             problems.append("alpha not restored")
         mean = got / np.float32(total)
