@@ -358,6 +358,26 @@ def test_full_size_split_invariance_256_frames(rtmi):
     assert 0.2 < mean.mean() < 2.0
 
 
+def test_work_list_dealt_32_pixels_to_a_wave(rtmi, oracle):
+    """The compacting pair deals its work list 64, 32 or 16 pixels to a wave by the list's length (64 above about
+    1.18 M entries on a 256-CU device, 16 below 0.59 M): the benchmark image takes the first, the reference scene at
+    1080p and every small test image the last.  This image lands in between, with more frames than the 16 its ring
+    then holds: bit for bit against the one-lane-per-pixel kernel, and rows of it against the oracle."""
+    case = dict(scene="spheres", pose=cases.BENCH_POSE, size=(1600, 900), rpp=1, max_bounce=8, first=1, n=40)
+    got = gpu_render(rtmi, case, 2)
+    n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
+    assert 18432 * 32 < n_hit < 18432 * 64, n_hit
+    again = gpu_render(rtmi, case, 1)
+    assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
+    assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
+    osc = cases.oracle_scene(case)
+    ofd = cases.oracle_frame_data(case, osc)
+    for y0 in (0, 450, 899):
+        want = oracle.render(ofd, osc, 1, 40, rows=(y0, y0 + 1))
+        assert np.array_equal(got["accum"][y0].view(np.uint32), want["accum"][y0].view(np.uint32)), y0
+        assert np.array_equal(got["chain_hash"][y0], want["chain_hash"][y0]), y0
+
+
 def test_full_size_mesh_scene_256_frames(rtmi):
     """Config C3 at its stated length (reference scene, 1080p, 256 frames, depth 8): one launch == four
     launches of 64 frames == the one-lane-per-pixel kernel, bit for bit.  256 frames take the wave-shared
