@@ -215,7 +215,9 @@ RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
  * no-allocation launch records an event of its context (created with the context), and the next one on that
  * GPU, if it runs on another stream, waits for it on the device first; so contexts on their own streams may
  * call in any order without synchronising, and simply take turns.  (A caller that puts several contexts on
- * the SAME stream handle it passed in gets the stream's own order.)  The kernel choice is that of
+ * the SAME stream handle it passed in gets the stream's own order.  A call on a stream in capture mode is
+ * recorded into the graph without these events: when the graph runs relative to other users of the work area is
+ * for its launcher to arrange.)  The kernel choice is that of
  * rtmi_set_variant, except that primary segments are never kept between launches. */
 #define RTMI_NOALLOC_MAX_PIXELS 2097152u   /* 2^21: covers 1920 x 1080; 8 MiB of device memory per GPU */
 RTMI_API int rtmi_render_frames_noalloc(rtmi_ctx *ctx, const rtmi_frame_data *fd,

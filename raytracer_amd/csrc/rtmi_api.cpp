@@ -458,11 +458,16 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         if (c->device >= kMaxDevices) return fail(c, RTMI_ERR_UNSUPPORTED, "rtmi_render_frames_noalloc: device %d beyond %d", c->device, kMaxDevices);
         std::lock_guard<std::mutex> guard(g_scratch_lock);
         ScratchUser &u = g_scratch_user[c->device];
-        if (u.ctx && u.stream != c->stream) e = hipStreamWaitEvent(c->stream, u.done, 0);
+        // A stream in capture mode runs nothing now: the launch becomes part of a graph, and when that graph
+        // runs relative to other users of the work area is for whoever launches it to arrange.
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        e = hipStreamIsCapturing(c->stream, &capture);
+        const bool live = e == hipSuccess && capture == hipStreamCaptureStatusNone;
+        if (e == hipSuccess && live && u.ctx && u.stream != c->stream) e = hipStreamWaitEvent(c->stream, u.done, 0);
         if (e == hipSuccess)
             e = c->fused ? rt_launch_render_fma(variant, c->validate, p, c->stream, cache) : rt_launch_render(variant, c->validate, p, c->stream, cache);
-        if (e == hipSuccess) e = hipEventRecord(c->ev_noalloc, c->stream);
-        if (e == hipSuccess) {
+        if (e == hipSuccess && live) e = hipEventRecord(c->ev_noalloc, c->stream);
+        if (e == hipSuccess && live) {
             u.ctx = c;
             u.stream = c->stream;
             u.done = c->ev_noalloc;

@@ -123,3 +123,52 @@ def test_limits_and_errors(rtmi):
         r.render_frames_noalloc(fd, 1, 1)
         with pytest.raises(rtmi.RtmiError):
             r.last_render_ms()               # the call records no timing events
+
+
+def test_under_stream_capture(rtmi):
+    """The callers the entry point exists for: a stream in capture mode, where an allocation (or any synchronising
+    call) would invalidate the capture.  The call is captured into a HIP graph on a caller-provided stream, the
+    graph is launched twice (frames 1-6 overwrite, so both launches produce the same image), and the result is the
+    image of the plain entry point.  Nothing runs at capture time: the image is still untouched when the capture ends."""
+    hip = C.CDLL("libamdhip64.so")
+    vp = C.c_void_p
+    hip.hipStreamCreate.argtypes = [C.POINTER(vp)]
+    hip.hipStreamBeginCapture.argtypes = [vp, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, C.POINTER(vp)]
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(vp), vp, vp, vp, C.c_size_t]
+    hip.hipGraphLaunch.argtypes = [vp, vp]
+    hip.hipStreamSynchronize.argtypes = [vp]
+    hip.hipGraphExecDestroy.argtypes = [vp]
+    hip.hipGraphDestroy.argtypes = [vp]
+    hip.hipStreamDestroy.argtypes = [vp]
+    case = dict(cases.CASES["c2_spheres_bench_pose"], size=(320, 180))
+    sc = cases.product_scene(case)
+    fd = rtmi.make_frame_data(320, 180, sc, rtmi.BENCH_POSE, 1, 8)
+    with rtmi.Renderer(320, 180, variant=2) as r:
+        r.upload_scene(sc)
+        r.render_frames(fd, 1, 6)
+        want = r.read_accum()
+    for variant in (2, 1):
+        with rtmi.Renderer(320, 180, variant=variant) as r:
+            r.upload_scene(sc)
+            stream = vp()
+            assert hip.hipStreamCreate(C.byref(stream)) == 0
+            r.set_stream(stream.value)
+            r.synchronize()
+            assert hip.hipStreamBeginCapture(stream, 2) == 0          # hipStreamCaptureModeRelaxed
+            r.render_frames_noalloc(fd, 1, 6)
+            graph = vp()
+            rc = hip.hipStreamEndCapture(stream, C.byref(graph))
+            assert rc == 0 and graph.value, "capture was invalidated (hipError %d)" % rc
+            assert not r.read_accum().any()                              # nothing has run yet
+            exe = vp()
+            assert hip.hipGraphInstantiate(C.byref(exe), graph, None, None, 0) == 0
+            for _ in range(2):
+                assert hip.hipGraphLaunch(exe, stream) == 0
+            assert hip.hipStreamSynchronize(stream) == 0
+            got = r.read_accum()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "variant %d" % variant
+            hip.hipGraphExecDestroy(exe)
+            hip.hipGraphDestroy(graph)
+            r.set_stream(None)
+            hip.hipStreamDestroy(stream)
