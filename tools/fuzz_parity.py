@@ -2,7 +2,9 @@
 limits, frame ranges and kernel variants, each rendered on the GPU with validation on and compared
 bit for bit (accumulation image, display image, primitive ids, id-chain hash, RNG state) with the CPU
 oracle.  Not part of the test suite (it runs as long as it is told to).
-usage: fuzz_parity.py [n_cases] [first_seed]"""
+usage: fuzz_parity.py [n_cases] [first_seed]
+RTMI_FUZZ_GLASS=1: every fourth sphere and mesh of the generated scenes transmits, and both sides run with the
+transmitting-material extension switched on (the kernels against the oracle's statement of the same rule)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +13,9 @@ import numpy as np
 import raytracer_amd as R
 import oracle_lib as O
 
+glass = os.environ.get("RTMI_FUZZ_GLASS") == "1"
+if glass:
+    O.lib().orc_set_transmission(1)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
@@ -21,7 +26,7 @@ for case in range(n_cases):
     grid = (int(rs.randint(1, 9)), int(rs.randint(max(1, n_mesh), 12))) if n_mesh else (0, 0)
     extent = float(rs.uniform(1.5, 6.0))
     rad = float(rs.uniform(0.1, 0.6))
-    scene, pose = R.scenes.stress_scene(n_sph, grid, n_mesh, seed=seed0 + case, extent=extent, radius_range=(0.3 * rad, rad))
+    scene, pose = R.scenes.stress_scene(n_sph, grid, n_mesh, seed=seed0 + case, extent=extent, radius_range=(0.3 * rad, rad), glass=glass)
     pos = tuple(float(v) for v in rs.uniform(-1.2 * extent, 1.2 * extent, size=3))
     yaw, pitch = float(rs.uniform(-180, 180)), float(rs.uniform(-80, 80))
     if rs.rand() < 0.5:
@@ -41,6 +46,7 @@ for case in range(n_cases):
     want = O.render(ofd, osc, first, n, accum=seed_acc)
     with R.Renderer(w, h, variant=variant) as r:
         r.set_acceleration(accel)
+        r.enable_transmission(glass)
         r.upload_scene(scene)
         r.enable_validation(True)
         if seed_acc is not None:
