@@ -378,6 +378,39 @@ def test_work_list_dealt_32_pixels_to_a_wave(rtmi, oracle):
         assert np.array_equal(got["chain_hash"][y0], want["chain_hash"][y0]), y0
 
 
+def test_sphere_candidates_evaluated_in_batches(rtmi, oracle):
+    """The sphere-only form of the compacting pair stashes a lane's candidate sphere and evaluates the stashed ones
+    of a wave together (when a lane holding one finds another, and at the end).  Three scenes that drive that
+    differently: 60 nested shells around the camera's target (every ray that reaches them is a candidate of each:
+    a flush per sphere), 150 small spheres far apart (hardly ever two for one ray: the final flush does the work),
+    and pairs of equal spheres at the same place (ties between candidates, which must fall to the lower index).
+    Whole images, every output, bit for bit against the oracle and against the one-lane-per-pixel kernel."""
+    rs = np.random.RandomState(77)
+    grey = lambda k: rtmi.material((0.5 + 0.4 * np.sin(k), 0.6, 0.5 + 0.4 * np.cos(k)), 2.0 if k % 9 == 0 else 0.0, 0.3 * (k % 3))
+    shells = [rtmi.sphere((0.0, 0.0, 0.0), 0.2 + 0.05 * k, grey(k)) for k in range(60)]
+    sparse = [rtmi.sphere(tuple(float(v) for v in rs.uniform(-12, 12, 3)), 0.25, grey(k)) for k in range(150)]
+    twins = []
+    for k in range(20):
+        c = tuple(float(v) for v in rs.uniform(-3, 3, 3))
+        twins += [rtmi.sphere(c, 0.7, grey(2 * k)), rtmi.sphere(c, 0.7, grey(2 * k + 1))]
+    for name, spheres, pos in (("shells", shells, (0.0, 0.5, 6.0)), ("sparse", sparse, (0.0, 0.0, 20.0)), ("twins", twins, (0.0, 1.0, 8.0))):
+        sc = rtmi.Scene(spheres)
+        osc = oracle.Scene.from_product(sc)
+        w, h = 160, 96
+        fd = rtmi.make_frame_data(w, h, sc, pose=(pos, -90.0, 0.0), rays_per_pixel=2, max_bounce=5)
+        ofd = oracle.frame_data(w, h, pos=pos, yaw=-90.0, pitch=0.0, rpp=2, max_bounce=5, scene=osc)
+        want = oracle.render(ofd, osc, 1, 5)
+        assert (want["prim_id"] != rtmi.abi.MISS_ID).sum() > 200, name
+        for variant in (2, 0):
+            with rtmi.Renderer(w, h, variant=variant) as r:
+                r.upload_scene(sc)
+                r.enable_validation(True)
+                r.render_frames(fd, 1, 5)
+                got = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                           chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state())
+            assert_same(got, want)
+
+
 def test_full_size_mesh_scene_256_frames(rtmi):
     """Config C3 at its stated length (reference scene, 1080p, 256 frames, depth 8): one launch == four
     launches of 64 frames == the one-lane-per-pixel kernel, bit for bit.  256 frames take the wave-shared
