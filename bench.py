@@ -133,8 +133,9 @@ def self_launch(n_gpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps (default 100: a timed region of 0.8 s on the default workload, long enough for a utilisation sampler to see it)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2_spheres", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256; 512 for c4, 64 for c1, 16 for c5)")
     ap.add_argument("--variant", type=int, default=None, choices=[0, 1, 2, 4],

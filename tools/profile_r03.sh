@@ -12,7 +12,7 @@ for wl in c2_spheres c3_mesh c4_mesh_4k c1_plumbing c5_stress; do
 done
 echo benches done
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/ks_bench -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/bench_under_trace.err || exit 1
-( echo "# python3 bench.py --no-cpu-baseline  (the default bench command: 2 warm-up + 10 timed launches of 256 frames, plus the two instrumented launches that count events)"; cat $(find $OUT/ks_bench -name "*kernel_stats.csv") ) > $OUT/kernel_stats_c2_spheres.csv
+( echo "# python3 bench.py --no-cpu-baseline  (the default bench command: 5 warm-up + 100 timed launches of 256 frames, plus the two instrumented launches that count events)"; cat $(find $OUT/ks_bench -name "*kernel_stats.csv") ) > $OUT/kernel_stats_c2_spheres.csv
 for wl in c3_mesh c4_mesh_4k c5_stress c1_plumbing; do
   v=2; [ $wl = c5_stress ] && v=4
   fr=256; [ $wl = c4_mesh_4k ] && fr=512; [ $wl = c5_stress ] && fr=16; [ $wl = c1_plumbing ] && fr=64
