@@ -980,6 +980,21 @@ const char *RT_SYM(rt_kernel_name)(int variant)
     }
 }
 
+// Workgroups of a k_paths launch: one single-wave workgroup per 64 list entries at least; the list's length is
+// only known on the device, so the grid covers the worst case and surplus workgroups leave at once.  k_paths may
+// deal a short list out 32 or 16 pixels to a wave: the grid allows for twice as many waves as 64 to a wave need,
+// four times as many for images up to 2^20 pixels, where surplus workgroups cost next to nothing.
+static uint32_t paths_grid(uint32_t n_pixels, bool bvh)
+{
+    const uint32_t per_group = bvh ? 64u : (n_pixels <= (1u << 20) ? 16u : 32u);
+    return (n_pixels + per_group - 1u) / per_group;
+}
+
+uint32_t RT_SYM(rt_paths_pixels_per_wave)(uint32_t n_pixels, uint32_t n_hit, uint32_t paths_per_pixel, uint32_t n_cus)
+{
+    return 1u << paths_pixel_shift(n_hit, paths_per_pixel, n_cus, paths_grid(n_pixels, false));
+}
+
 hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)
 {
     if (p.width == 0 || p.height == 0 || p.n_frames == 0) return hipErrorInvalidValue;
@@ -1039,14 +1054,8 @@ hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderPara
     } else if (variant == 2) {
         if (!p.hit_list || !p.hit_count) return hipErrorInvalidValue;
         if (cache != RT_CACHE_NONE && (validate || !p.primary || !p.primary_mat)) return hipErrorInvalidValue;
-        // one single-wave workgroup per 64 list entries; the list length is only known on the device,
-        // so the grid covers the worst case and surplus workgroups leave at once
-        // (k_paths may deal a short list out 32 or 16 pixels to a wave: the grid allows for twice as many
-        // waves as 64 to a wave need, four times as many for images up to 2^20 pixels, where surplus
-        // workgroups cost next to nothing)
         const uint32_t n_pixels = p.width * p.height;
-        const uint32_t per_group = bvh ? 64u : (n_pixels <= (1u << 20) ? 16u : 32u);
-        const dim3 grid_paths((n_pixels + per_group - 1u) / per_group, 1, 1);
+        const dim3 grid_paths(paths_grid(n_pixels, bvh), 1, 1);
         const dim3 block_paths(kPathsThreads, 1, 1);
         // k_paths for this scene: with a hierarchy, without meshes (no mesh code at all), or with meshes
         // (triangle tests shared by the lanes of a wave)

@@ -782,6 +782,14 @@ int rtmi_reset_counters(rtmi_ctx *c)
 
 int rtmi_bvh_node_bytes(void) { return (int)sizeof(rtmi::QNode); }
 
+int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t *out)
+{
+    if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL context");
+    if (!out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
+    *out = rt_paths_pixels_per_wave((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel, (uint32_t)c->n_cus);
+    return RTMI_OK;
+}
+
 int rtmi_device_count(void)
 {
     int count = 0;

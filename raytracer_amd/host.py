@@ -380,6 +380,12 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
+    def paths_pixels_per_wave(self, n_listed, n_frames, rays_per_pixel=1):
+        """Pixels per wave (64, 32, 16) the compacting pair takes for a work list of n_listed pixels (rtmi_paths_pixels_per_wave)."""
+        out = C.c_uint32(0)
+        self._check(self._lib.rtmi_paths_pixels_per_wave(self._ctx, n_listed, n_frames, rays_per_pixel, C.byref(out)))
+        return int(out.value)
+
     def selftest_walk(self, sphere_number, mesh_number, origins, directions, repeats=1):
         """(t, prim_id, ms): the rays, in the order given, through the walk-only streaming kernel (hierarchy scenes)."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -358,24 +358,51 @@ def test_full_size_split_invariance_256_frames(rtmi):
     assert 0.2 < mean.mean() < 2.0
 
 
+def _pixels_per_wave(rtmi, size, n_listed, n_frames):
+    with rtmi.Renderer(size[0], size[1]) as r:
+        return r.paths_pixels_per_wave(n_listed, n_frames)
+
+
 def test_work_list_dealt_32_pixels_to_a_wave(rtmi, oracle):
-    """The compacting pair deals its work list 64, 32 or 16 pixels to a wave by the list's length (64 above about
-    1.18 M entries on a 256-CU device, 16 below 0.59 M): the benchmark image takes the first, the reference scene at
-    1080p and every small test image the last.  This image lands in between, with more frames than the 16 its ring
-    then holds: bit for bit against the one-lane-per-pixel kernel, and rows of it against the oracle."""
-    case = dict(scene="spheres", pose=cases.BENCH_POSE, size=(1600, 900), rpp=1, max_bounce=8, first=1, n=40)
+    """The compacting pair deals its work list 64, 32 or 16 pixels to a wave, by the list's length and the
+    launch's frame count (rtmi_paths_pixels_per_wave tells which): the benchmark image takes 64, the reference scene
+    at 1080p over 256 frames and the small test images over enough frames 16.  This image over 200 frames lands in
+    between, with more frames than the 16 its ring then holds: bit for bit against the one-lane-per-pixel kernel, and
+    rows of it against the oracle."""
+    case = dict(scene="spheres", pose=cases.BENCH_POSE, size=(1600, 900), rpp=1, max_bounce=8, first=1, n=200)
     got = gpu_render(rtmi, case, 2)
     n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
-    assert 18432 * 32 < n_hit < 18432 * 64, n_hit
+    assert _pixels_per_wave(rtmi, case["size"], n_hit, case["n"]) == 32, n_hit
     again = gpu_render(rtmi, case, 1)
     assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
     assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
     osc = cases.oracle_scene(case)
     ofd = cases.oracle_frame_data(case, osc)
     for y0 in (0, 450, 899):
-        want = oracle.render(ofd, osc, 1, 40, rows=(y0, y0 + 1))
+        want = oracle.render(ofd, osc, 1, case["n"], rows=(y0, y0 + 1))
         assert np.array_equal(got["accum"][y0].view(np.uint32), want["accum"][y0].view(np.uint32)), y0
         assert np.array_equal(got["chain_hash"][y0], want["chain_hash"][y0]), y0
+
+
+def test_pixels_per_wave_by_list_length_and_frame_count(rtmi, oracle):
+    """The same image and scene rendered over 1, 6 and 96 frames takes 64, 32 and 16 pixels to a wave (few frames
+    would leave lanes of a short wave without items; many frames make more, shorter waves worth their set-up): each
+    against the oracle, whole image, every output.  And what the choice does at the benchmark sizes."""
+    seen = set()
+    for n in (1, 6, 96):
+        case = dict(scene="reference", pose=cases.BENCH_POSE, size=(640, 360), rpp=1, max_bounce=4, first=1, n=n)
+        got = gpu_render(rtmi, case, 2)
+        n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
+        seen.add(_pixels_per_wave(rtmi, case["size"], n_hit, n))
+        osc = cases.oracle_scene(case)
+        want = oracle.render(cases.oracle_frame_data(case, osc), osc, 1, n)
+        assert_same({k: v for k, v in got.items() if k != "counters"}, want)
+    assert 16 in seen and len(seen) >= 2, seen
+    # 1080p: the spheres scene lists every pixel below the horizon and more (5.3 rounds of wave slots at 64 to a wave)
+    assert _pixels_per_wave(rtmi, (1920, 1080), 2000000, 256) == 64
+    # the reference scene lists about 0.56 M pixels: 16 to a wave over 256 frames, 64 over 8
+    assert _pixels_per_wave(rtmi, (1920, 1080), 560000, 256) == 16
+    assert _pixels_per_wave(rtmi, (1920, 1080), 560000, 8) == 64
 
 
 def test_sphere_candidates_evaluated_in_batches(rtmi, oracle):
