@@ -344,13 +344,14 @@ RTMI_API int rtmi_selftest_exhaustive(rtmi_ctx *ctx, int op, float divisor, uint
 RTMI_API int rtmi_selftest_closest_hit(rtmi_ctx *ctx, uint32_t sphere_number, uint32_t mesh_number,
                                        const float *origins, const float *directions, size_t n,
                                        float *t_out, uint32_t *prim_out);
-/* How many pixels (64, 32 or 16) RTMI_VARIANT_COMPACT deals to a wave on this context's device and image size when
- * its work list holds n_listed pixels and the launch renders n_frames frames of rays_per_pixel samples: the same
- * function the kernel evaluates.  The choice changes how the work is spread, never a result; tests use this to
- * know which form a configuration exercises.  No counterpart in the reference (the shader's work groups are fixed,
- * Raytracing.comp:89). */
+/* How RTMI_VARIANT_COMPACT deals its work list to waves on this context's device and image size when the list
+ * holds n_listed pixels and the launch renders n_frames frames of rays_per_pixel samples of a scene with mesh_number
+ * meshes (without a hierarchy): pixels per wave (64, 32 or 16), and whether a wave's pixels are neighbours in the
+ * list (1) or spread evenly over it (0).  The same function the kernel evaluates.  The choice changes how the work
+ * is spread, never a result; tests use this to know which form a configuration exercises.  No counterpart in the
+ * reference (the shader's work groups are fixed, Raytracing.comp:89). */
 RTMI_API int rtmi_paths_pixels_per_wave(rtmi_ctx *ctx, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel,
-                                        uint32_t *out);
+                                        uint32_t mesh_number, uint32_t *pixels_out, int *neighbours_out);
 /* The same question, for a scene with a hierarchy, answered by a kernel that does nothing but walk: persistent
  * waves whose lanes take ray after ray (in the order given) and resume their walks as the path kernels do.  Same
  * results; *ms_out receives the shortest of `repeats` launches.  A measurement hook: what the walks of a set of

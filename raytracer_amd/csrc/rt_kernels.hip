@@ -990,9 +990,9 @@ static uint32_t paths_grid(uint32_t n_pixels, bool bvh)
     return (n_pixels + per_group - 1u) / per_group;
 }
 
-uint32_t RT_SYM(rt_paths_pixels_per_wave)(uint32_t n_pixels, uint32_t n_hit, uint32_t paths_per_pixel, uint32_t n_cus)
+uint32_t RT_SYM(rt_paths_deal)(uint32_t n_pixels, uint32_t n_hit, uint32_t paths_per_pixel, uint32_t n_cus, bool meshes)
 {
-    return 1u << paths_pixel_shift(n_hit, paths_per_pixel, n_cus, paths_grid(n_pixels, false));
+    return paths_deal(n_hit, paths_per_pixel, n_cus, paths_grid(n_pixels, false), meshes);
 }
 
 hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)

@@ -141,6 +141,11 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
+// paths per pixel and launch from which RTMI_VARIANT_AUTO takes the compacting pair (measurements where it is used)
+#ifndef RTMI_AUTO_COMPACT_FROM
+#define RTMI_AUTO_COMPACT_FROM 8
+#endif
+constexpr uint64_t kAutoCompactFrom = RTMI_AUTO_COMPACT_FROM;
 // primitive count above which RTMI_ACCEL_AUTO builds hierarchies
 // (measured on random sphere scenes at 1080p: the hierarchy overtakes the exhaustive loops between 256 and
 // 512 primitives)
@@ -410,7 +415,7 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // streaming kernels only, and starts from nothing stored
         const bool glass = c->dscene.has_glass != 0u;
         const bool use_store = compact_runs && !c->validate && !stream && !no_alloc && !glass;
-        const bool compact = !stream && paths_per_pixel >= 8u && !glass;
+        const bool compact = !stream && paths_per_pixel >= kAutoCompactFrom && !glass;
         if (use_store) {
             const size_t np = n_pixels(c);
             if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));
@@ -782,11 +787,14 @@ int rtmi_reset_counters(rtmi_ctx *c)
 
 int rtmi_bvh_node_bytes(void) { return (int)sizeof(rtmi::QNode); }
 
-int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t *out)
+int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t mesh_number,
+                               uint32_t *pixels_out, int *neighbours_out)
 {
     if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL context");
-    if (!out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
-    *out = rt_paths_pixels_per_wave((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel, (uint32_t)c->n_cus);
+    if (!pixels_out || !neighbours_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
+    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel, (uint32_t)c->n_cus, mesh_number != 0u);
+    *pixels_out = 1u << (deal & 255u);
+    *neighbours_out = (deal & 256u) != 0u;
     return RTMI_OK;
 }
 

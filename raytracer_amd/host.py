@@ -380,11 +380,12 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
-    def paths_pixels_per_wave(self, n_listed, n_frames, rays_per_pixel=1):
-        """Pixels per wave (64, 32, 16) the compacting pair takes for a work list of n_listed pixels (rtmi_paths_pixels_per_wave)."""
-        out = C.c_uint32(0)
-        self._check(self._lib.rtmi_paths_pixels_per_wave(self._ctx, n_listed, n_frames, rays_per_pixel, C.byref(out)))
-        return int(out.value)
+    def paths_pixels_per_wave(self, n_listed, n_frames, rays_per_pixel=1, mesh_number=0):
+        """(pixels per wave, neighbours?) the compacting pair takes for a work list of n_listed pixels (rtmi_paths_pixels_per_wave)."""
+        pixels, together = C.c_uint32(0), C.c_int(0)
+        self._check(self._lib.rtmi_paths_pixels_per_wave(self._ctx, n_listed, n_frames, rays_per_pixel, mesh_number,
+                                                         C.byref(pixels), C.byref(together)))
+        return int(pixels.value), bool(together.value)
 
     def selftest_walk(self, sphere_number, mesh_number, origins, directions, repeats=1):
         """(t, prim_id, ms): the rays, in the order given, through the walk-only streaming kernel (hierarchy scenes)."""

@@ -358,9 +358,10 @@ def test_full_size_split_invariance_256_frames(rtmi):
     assert 0.2 < mean.mean() < 2.0
 
 
-def _pixels_per_wave(rtmi, size, n_listed, n_frames):
+def _deal(rtmi, size, n_listed, n_frames, mesh_number=0):
+    """(pixels per wave, neighbours in the list?) of the compacting pair for such a launch"""
     with rtmi.Renderer(size[0], size[1]) as r:
-        return r.paths_pixels_per_wave(n_listed, n_frames)
+        return r.paths_pixels_per_wave(n_listed, n_frames, 1, mesh_number)
 
 
 def test_work_list_dealt_32_pixels_to_a_wave(rtmi, oracle):
@@ -372,7 +373,7 @@ def test_work_list_dealt_32_pixels_to_a_wave(rtmi, oracle):
     case = dict(scene="spheres", pose=cases.BENCH_POSE, size=(1600, 900), rpp=1, max_bounce=8, first=1, n=200)
     got = gpu_render(rtmi, case, 2)
     n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
-    assert _pixels_per_wave(rtmi, case["size"], n_hit, case["n"]) == 32, n_hit
+    assert _deal(rtmi, case["size"], n_hit, case["n"]) == (32, False), n_hit
     again = gpu_render(rtmi, case, 1)
     assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
     assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
@@ -393,16 +394,44 @@ def test_pixels_per_wave_by_list_length_and_frame_count(rtmi, oracle):
         case = dict(scene="reference", pose=cases.BENCH_POSE, size=(640, 360), rpp=1, max_bounce=4, first=1, n=n)
         got = gpu_render(rtmi, case, 2)
         n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
-        seen.add(_pixels_per_wave(rtmi, case["size"], n_hit, n))
+        pixels, together = _deal(rtmi, case["size"], n_hit, n, 2)
+        assert not together      # far too short a list
+        seen.add(pixels)
         osc = cases.oracle_scene(case)
         want = oracle.render(cases.oracle_frame_data(case, osc), osc, 1, n)
         assert_same({k: v for k, v in got.items() if k != "counters"}, want)
     assert 16 in seen and len(seen) >= 2, seen
     # 1080p: the spheres scene lists every pixel below the horizon and more (5.3 rounds of wave slots at 64 to a wave)
-    assert _pixels_per_wave(rtmi, (1920, 1080), 2000000, 256) == 64
-    # the reference scene lists about 0.56 M pixels: 16 to a wave over 256 frames, 64 over 8
-    assert _pixels_per_wave(rtmi, (1920, 1080), 560000, 256) == 16
-    assert _pixels_per_wave(rtmi, (1920, 1080), 560000, 8) == 64
+    assert _deal(rtmi, (1920, 1080), 2000000, 256) == (64, False)
+    # the reference scene lists about 0.56 M pixels: 16 neighbours to a wave over 256 frames, 64 spread ones over 8
+    assert _deal(rtmi, (1920, 1080), 560000, 256, 2) == (16, True)
+    assert _deal(rtmi, (1920, 1080), 560000, 8, 2) == (64, False)
+    assert _deal(rtmi, (1920, 1080), 560000, 256, 0) == (16, False)   # the sphere-only kernel never takes neighbours
+
+
+def test_waves_of_neighbouring_pixels(rtmi, oracle):
+    """With meshes and a list that fills the device's wave slots four times or more, a wave takes neighbouring list
+    entries (the reference scene at 3840x2160 over 8 frames: 32 to a wave): bit for bit against the one-lane-per-pixel
+    kernel, rows against the oracle.  (16 neighbours: the 256-frame test of the reference scene at 1080p; 64: the
+    four-frame test at 3840x2160.)"""
+    case = dict(scene="reference", pose=cases.BENCH_POSE, size=(3840, 2160), rpp=1, max_bounce=8, first=1, n=8)
+    got = gpu_render(rtmi, case, 2)
+    n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
+    assert _deal(rtmi, case["size"], n_hit, case["n"], 2) == (32, True), n_hit
+    assert _deal(rtmi, case["size"], n_hit, 4, 2) == (64, True)
+    assert _deal(rtmi, (1920, 1080), n_hit // 4, 256, 2) == (16, True)
+    again = gpu_render(rtmi, case, 1)
+    assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
+    assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
+    del again
+    osc = cases.oracle_scene(case)
+    ofd = cases.oracle_frame_data(case, osc)
+    for y0 in (0, 1100, 2159):
+        want = oracle.render(ofd, osc, 1, case["n"], rows=(y0, y0 + 1))
+        for k in ("accum", "rgba8", "prim_id", "chain_hash", "rng_state"):
+            same = np.array_equal(got[k][y0].view(np.uint32) if k == "accum" else got[k][y0],
+                                  want[k][y0].view(np.uint32) if k == "accum" else want[k][y0])
+            assert same, (k, y0)
 
 
 def test_sphere_candidates_evaluated_in_batches(rtmi, oracle):

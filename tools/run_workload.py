@@ -9,7 +9,9 @@ import raytracer_amd as R
 WORKLOADS = {"c2_spheres": ("spheres", 1920, 1080, 8), "c3_mesh": ("reference", 1920, 1080, 8),
              "c4_mesh_4k": ("reference", 3840, 2160, 8), "c1_plumbing": ("reference", 640, 360, 4),
              "c5_stress": ("stress", 1920, 1080, 16), "c5_small": ("stress_small", 1920, 1080, 16),
-             "c5_stress_glass": ("stress_glass", 1920, 1080, 16)}
+             "c5_stress_glass": ("stress_glass", 1920, 1080, 16),
+             # the reference scene at sizes between C1 and C3 (tuning of the work-list dealing)
+             "ref_720p": ("reference", 1280, 720, 8), "ref_540p": ("reference", 960, 540, 8), "ref_1440p": ("reference", 2560, 1440, 8)}
 name = sys.argv[1] if len(sys.argv) > 1 else "c2_spheres"
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
