@@ -100,10 +100,11 @@ typedef enum rtmi_variant {
     RTMI_VARIANT_COMPACT    = 2,   /* the primary segment (identical for every sample of a pixel, RT.comp:449-453)
                                       is evaluated once per launch; pixels that see only sky are finished at once, the
                                       others are stream-compacted (wave ballot + prefix count) and traced by dense waves */
-    RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 8 paths per pixel
-                                      (frames x rays per pixel), REGENERATE otherwise (COMPACT spends about 0.15 ms
-                                      per 1080p launch on classification, which a one-frame launch, the reference's
-                                      own calling pattern, does not earn back); with a hierarchy, STREAM.
+    RTMI_VARIANT_AUTO       = 3,   /* default: per launch, COMPACT when the launch holds at least 8 frames (4 for images
+                                      up to 2^21 pixels), REGENERATE otherwise: COMPACT hands out work by the frame (the
+                                      samples of a frame share a random number stream and stay with one lane), so a launch
+                                      of few frames, the reference's own calling pattern, leaves its lanes idle however
+                                      many rays per pixel a frame has; with a hierarchy, STREAM.
                                       While the uniform block (apart from frame_index) and the scene stay the same
                                       from launch to launch, AUTO also keeps every pixel's primary segment and lets
                                       later launches start from it; results are the same bits either way */

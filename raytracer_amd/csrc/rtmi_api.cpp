@@ -141,11 +141,12 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
-// paths per pixel and launch from which RTMI_VARIANT_AUTO takes the compacting pair (measurements where it is used)
-#ifndef RTMI_AUTO_COMPACT_FROM
-#define RTMI_AUTO_COMPACT_FROM 8
+// frames per launch from which RTMI_VARIANT_AUTO takes the compacting pair (measurements where it is used); half as
+// many for images up to 2^21 pixels
+#ifndef RTMI_AUTO_COMPACT_FRAMES
+#define RTMI_AUTO_COMPACT_FRAMES 8
 #endif
-constexpr uint64_t kAutoCompactFrom = RTMI_AUTO_COMPACT_FROM;
+constexpr uint32_t kAutoCompactFrames = RTMI_AUTO_COMPACT_FRAMES;
 // primitive count above which RTMI_ACCEL_AUTO builds hierarchies
 // (measured on random sphere scenes at 1080p: the hierarchy overtakes the exhaustive loops between 256 and
 // 512 primitives)
@@ -398,15 +399,16 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     rtmi_frame_data key = *fd;
     key.frame_index = 0;
     if (variant == RTMI_VARIANT_AUTO) {
-        // measured at 1080p (spheres scene, without stored hits): 4 paths per pixel per launch REGENERATE 0.30 ms
-        // against COMPACT's 0.34, 8 paths 0.54 against 0.48, 16 paths 1.01 against 0.76
-        const uint64_t paths_per_pixel = (uint64_t)n_frames * fd->rays_per_pixel;
+        // The compacting pair hands out work by the frame: the samples of one frame of a pixel share a random number
+        // stream (Raytracing.comp:464-468) and stay with one lane.  With few frames in a launch its lanes run dry
+        // while the longest pixel finishes, however many samples a frame has, and the one-lane-per-pixel kernel,
+        // whose waves hold neighbouring pixels of similar cost, is ahead: measured on both benchmark scenes at
+        // 1280x720, 1080p and 3840x2160 from stored hits, 1 frame of 8 / 16 samples 250-2240 us against the pair's
+        // 370-4540, 2 frames of 4 about 20 % ahead; 4 frames a tie up to 1080p (+-4 %) and 13-17 % ahead at
+        // 3840x2160; from 8 frames on the pair wins everywhere (8 frames of 1 sample: 136-1202 against 216-1285 us).
         const bool compact_runs = fd->max_bounce_limit >= 2 && fd->rays_per_pixel >= 1;  // else the launcher falls back
         const bool same_as_stored = c->cache_valid && c->cache_generation == c->scene_generation &&
                                     memcmp(&key, &c->cache_key, sizeof key) == 0;
-        // Starting from stored primary hits removes COMPACT's fixed cost, which moves its break-even from
-        // 8 to about 4 paths per pixel per launch (spheres scene, 8 paths: 0.46 ms against REGENERATE's
-        // 0.59; 2 paths: 0.23 against 0.20); below 8 the one-lane-per-pixel kernel starts from them.
         // With a hierarchy the pixel-streaming kernel is ahead at every launch size (10^6 + 10^6 primitive
         // scene at 1080p: 1 frame 11.4 ms against COMPACT's 27, 8 frames 80 against 93, 16 frames 158 against
         // 172, 64 frames 630 against 643); it starts from nothing stored.
@@ -415,7 +417,8 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
         // streaming kernels only, and starts from nothing stored
         const bool glass = c->dscene.has_glass != 0u;
         const bool use_store = compact_runs && !c->validate && !stream && !no_alloc && !glass;
-        const bool compact = !stream && paths_per_pixel >= kAutoCompactFrom && !glass;
+        const bool compact = !stream && !glass &&
+                             (n_frames >= kAutoCompactFrames || (2u * n_frames >= kAutoCompactFrames && n_pixels(c) <= (size_t(1) << 21)));
         if (use_store) {
             const size_t np = n_pixels(c);
             if (!c->primary) HIP_TRY(c, hipMalloc(&c->primary, np * sizeof(float4)));

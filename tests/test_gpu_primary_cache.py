@@ -57,7 +57,11 @@ def test_store_use_and_invalidation(rtmi):
         frame = 0
         for _ in range(4):
             step()
-        step(20)                                    # a large launch stores as it goes
+        step(20)                                    # a long launch goes to the compacting pair, which stores as it goes
+        step(20)                                    # and starts from the store and its work list the next time
+        step(8)
+        step(4)                                     # a small image: the pair from four frames on
+        step(3)                                     # fewer: the one-lane-per-pixel kernel, from the same store
         step(2)
         # an explicit variant-2 launch rebuilds the work list; the next default launch must not trust the store
         auto.set_variant(rtmi.abi.VARIANT_COMPACT)
