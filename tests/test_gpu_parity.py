@@ -409,25 +409,30 @@ def test_pixels_per_wave_by_list_length_and_frame_count(rtmi, oracle):
     assert _deal(rtmi, (1920, 1080), 560000, 256, 0) == (16, False)   # the sphere-only kernel never takes neighbours
 
 
-def test_waves_of_neighbouring_pixels(rtmi, oracle):
+@pytest.mark.parametrize("size,n,want_deal,rows", [((3840, 2160), 8, (32, True), (0, 1100, 2159)),
+                                                   ((1280, 720), 64, (8, True), (0, 400, 719))])
+def test_waves_of_neighbouring_pixels(rtmi, oracle, size, n, want_deal, rows):
     """With meshes and a list that fills the device's wave slots four times or more, a wave takes neighbouring list
-    entries (the reference scene at 3840x2160 over 8 frames: 32 to a wave): bit for bit against the one-lane-per-pixel
-    kernel, rows against the oracle.  (16 neighbours: the 256-frame test of the reference scene at 1080p; 64: the
-    four-frame test at 3840x2160.)"""
-    case = dict(scene="reference", pose=cases.BENCH_POSE, size=(3840, 2160), rpp=1, max_bounce=8, first=1, n=8)
+    entries: the reference scene at 3840x2160 over 8 frames 32 to a wave, at 1280x720 over 64 frames 8 to a wave (16
+    would make too few waves).  Bit for bit against the one-lane-per-pixel kernel, rows against the oracle.
+    (16 neighbours: the 256-frame test of the reference scene at 1080p; 64: the four-frame test at 3840x2160.)"""
+    case = dict(scene="reference", pose=cases.BENCH_POSE, size=size, rpp=1, max_bounce=8, first=1, n=n)
     got = gpu_render(rtmi, case, 2)
     n_hit = int((got["prim_id"] != rtmi.abi.MISS_ID).sum())
-    assert _deal(rtmi, case["size"], n_hit, case["n"], 2) == (32, True), n_hit
-    assert _deal(rtmi, case["size"], n_hit, 4, 2) == (64, True)
-    assert _deal(rtmi, (1920, 1080), n_hit // 4, 256, 2) == (16, True)
+    assert _deal(rtmi, size, n_hit, n, 2) == want_deal, n_hit
+    if size == (3840, 2160):
+        assert _deal(rtmi, size, n_hit, 4, 2) == (64, True)
+        assert _deal(rtmi, (1920, 1080), n_hit // 4, 256, 2) == (16, True)
+    else:
+        assert _deal(rtmi, size, n_hit, 16, 2)[1] is False      # 8 to a wave would leave two paths per lane
     again = gpu_render(rtmi, case, 1)
     assert cases.bits_equal(got["accum"], again["accum"]) and got["counters"] == again["counters"]
     assert np.array_equal(got["chain_hash"], again["chain_hash"]) and np.array_equal(got["rng_state"], again["rng_state"])
     del again
     osc = cases.oracle_scene(case)
     ofd = cases.oracle_frame_data(case, osc)
-    for y0 in (0, 1100, 2159):
-        want = oracle.render(ofd, osc, 1, case["n"], rows=(y0, y0 + 1))
+    for y0 in rows:
+        want = oracle.render(ofd, osc, 1, n, rows=(y0, y0 + 1))
         for k in ("accum", "rgba8", "prim_id", "chain_hash", "rng_state"):
             same = np.array_equal(got[k][y0].view(np.uint32) if k == "accum" else got[k][y0],
                                   want[k][y0].view(np.uint32) if k == "accum" else want[k][y0])
