@@ -345,6 +345,11 @@ RTMI_API int rtmi_selftest_exhaustive(rtmi_ctx *ctx, int op, float divisor, uint
 RTMI_API int rtmi_selftest_closest_hit(rtmi_ctx *ctx, uint32_t sphere_number, uint32_t mesh_number,
                                        const float *origins, const float *directions, size_t n,
                                        float *t_out, uint32_t *prim_out);
+/* What the library's scheduling decisions take for the number of compute units of the device from now on (0 = what
+ * the device reports, the default): how RTMI_VARIANT_COMPACT deals its work list to waves, how many persistent waves
+ * RTMI_VARIANT_STREAM starts.  Never changes a result.  A test hook: with a small number, small images go through the
+ * forms that only large ones take on a real device.  No counterpart in the reference. */
+RTMI_API int rtmi_assume_compute_units(rtmi_ctx *ctx, int n);
 /* How RTMI_VARIANT_COMPACT deals its work list to waves on this context's device and image size when the list
  * holds n_listed pixels and the launch renders n_frames frames of rays_per_pixel samples of a scene with mesh_number
  * meshes (without a hierarchy): pixels per wave (64, 32, 16 or 8), and whether a wave's pixels are neighbours in the

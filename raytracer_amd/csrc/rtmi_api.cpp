@@ -58,6 +58,7 @@ struct rtmi_ctx {
     uint32_t *hit_list = nullptr, *hit_count = nullptr;  // variant 2 work list; hit_count[16] is variant 4's cursor
     uint32_t *scratch = nullptr;   // this device's copy of the library's static work area (rtmi_render_frames_noalloc)
     int n_cus = 0;
+    int assumed_cus = 0;   // rtmi_assume_compute_units: what the scheduling decisions take for the device's size (0 = n_cus)
     // Primary-segment cache (RTMI_VARIANT_AUTO only).  With an unchanged camera, scene and frame
     // constants every launch would classify the same pixels and find the same primary hits; they are
     // stored once (with the work list) and later launches start from them.  The key is the whole
@@ -388,7 +389,7 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     p.hit_list = no_alloc ? c->scratch + kScratchHeadWords : c->hit_list;
     p.hit_count = no_alloc ? c->scratch : c->hit_count;
     p.stream_cursor = p.hit_count + 16;
-    p.n_cus = (uint32_t)c->n_cus;
+    p.n_cus = (uint32_t)(c->assumed_cus > 0 ? c->assumed_cus : c->n_cus);
     p.chain_hash = c->chain_hash;
     p.rng_state = c->rng_state;
     p.counters = c->counters;
@@ -790,12 +791,21 @@ int rtmi_reset_counters(rtmi_ctx *c)
 
 int rtmi_bvh_node_bytes(void) { return (int)sizeof(rtmi::QNode); }
 
+int rtmi_assume_compute_units(rtmi_ctx *c, int n)
+{
+    if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_assume_compute_units: NULL context");
+    if (n < 0 || n > 65536) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_assume_compute_units: %d is not a number of compute units", n);
+    c->assumed_cus = n;
+    return RTMI_OK;
+}
+
 int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t mesh_number,
                                uint32_t *pixels_out, int *neighbours_out)
 {
     if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL context");
     if (!pixels_out || !neighbours_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
-    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel, (uint32_t)c->n_cus, mesh_number != 0u);
+    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel,
+                                        (uint32_t)(c->assumed_cus > 0 ? c->assumed_cus : c->n_cus), mesh_number != 0u);
     *pixels_out = 1u << (deal & 255u);
     *neighbours_out = (deal & 256u) != 0u;
     return RTMI_OK;

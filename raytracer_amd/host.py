@@ -380,6 +380,10 @@ class Renderer:
                                                         d.ctypes.data, len(o), t.ctypes.data, prim.ctypes.data))
         return t, prim
 
+    def assume_compute_units(self, n):
+        """Scheduling decisions take the device to have n compute units (0 = what it reports); results never change."""
+        self._check(self._lib.rtmi_assume_compute_units(self._ctx, int(n)))
+
     def paths_pixels_per_wave(self, n_listed, n_frames, rays_per_pixel=1, mesh_number=0):
         """(pixels per wave, neighbours?) the compacting pair takes for a work list of n_listed pixels (rtmi_paths_pixels_per_wave)."""
         pixels, together = C.c_uint32(0), C.c_int(0)

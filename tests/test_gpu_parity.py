@@ -439,6 +439,35 @@ def test_waves_of_neighbouring_pixels(rtmi, oracle, size, n, want_deal, rows):
             assert same, (k, y0)
 
 
+@pytest.mark.parametrize("size,n,cus,want_deal", [((128, 72), 24, 1, (16, True)), ((128, 72), 32, 2, (8, True)),
+                                                  ((256, 144), 4, 1, (64, True)), ((256, 144), 8, 2, (32, True)),
+                                                  ((128, 72), 24, 64, (16, False)), ((128, 72), 24, 0, None)])
+def test_every_way_of_dealing_work_on_a_device_taken_to_be_small(rtmi, oracle, size, n, cus, want_deal):
+    """rtmi_assume_compute_units makes the scheduling decisions for a device of that many compute units, so that a
+    small image goes through the forms that only large ones take on the real device: waves of 64, 32, 16 and 8
+    neighbouring pixels, and the spread form.  Whole image, every output, against the oracle; the event counters
+    against the one-lane-per-pixel kernel."""
+    case = dict(scene="reference", pose=cases.BENCH_POSE, size=size, rpp=1, max_bounce=6, first=1, n=n)
+    sc = cases.product_scene(case)
+    fd = cases.product_frame_data(case, sc)
+    osc = cases.oracle_scene(case)
+    want = oracle.render(cases.oracle_frame_data(case, osc), osc, 1, n)
+    n_hit = int((want["prim_id"] != rtmi.abi.MISS_ID).sum())
+    got = {}
+    for variant in (2, 1):
+        with rtmi.Renderer(size[0], size[1], variant=variant) as r:
+            r.assume_compute_units(cus)
+            if variant == 2 and want_deal is not None:
+                assert r.paths_pixels_per_wave(n_hit, n, 1, 2) == want_deal, n_hit
+            r.upload_scene(sc)
+            r.enable_validation(True)
+            r.render_frames(fd, 1, n)
+            got[variant] = dict(accum=r.read_accum(), rgba8=r.read_output_rgba8(), prim_id=r.read_hit_ids(),
+                                chain_hash=r.read_chain_hash(), rng_state=r.read_rng_state(), counters=r.counters())
+    assert got[2]["counters"] == got[1]["counters"]
+    assert_same({k: v for k, v in got[2].items() if k != "counters"}, want)
+
+
 def test_sphere_candidates_evaluated_in_batches(rtmi, oracle):
     """The sphere-only form of the compacting pair stashes a lane's candidate sphere and evaluates the stashed ones
     of a wave together (when a lane holding one finds another, and at the end).  Three scenes that drive that

@@ -33,9 +33,12 @@ for case in range(n_cases):
         pos, yaw, pitch = pose                      # the generator's own view of the scene
     w, h = int(rs.choice([8, 23, 40, 64, 128])), int(rs.choice([8, 17, 36, 72]))
     rpp, mb = int(rs.choice([1, 1, 2, 3, 5])), int(rs.choice([0, 1, 2, 3, 6, 16]))
-    first, n = int(rs.choice([1, 1, 2, 9])), int(rs.choice([1, 2, 5, 11]))
+    first, n = int(rs.choice([1, 1, 2, 9])), int(rs.choice([1, 2, 5, 11, 40]))
     accel = int(rs.choice([R.abi.ACCEL_NONE, R.abi.ACCEL_BVH]))
     variant = int(rs.choice([0, 1, 2, 3, 4]))        # 3 chooses per launch and keeps primary hits between launches
+    # a device taken to be small sends these small images through every way of dealing work to waves (neighbouring
+    # or spread pixels, 64 .. 8 to a wave, few persistent waves)
+    cus = int(rs.choice([0, 0, 1, 1, 2, 4, 16]))
     osc = O.Scene.from_product(scene)
     fd = R.make_frame_data(w, h, scene, pose=(pos, yaw, pitch), rays_per_pixel=rpp, max_bounce=mb)
     ofd = O.frame_data(w, h, pos=pos, yaw=yaw, pitch=pitch, rpp=rpp, max_bounce=mb, scene=osc)
@@ -47,6 +50,7 @@ for case in range(n_cases):
     with R.Renderer(w, h, variant=variant) as r:
         r.set_acceleration(accel)
         r.enable_transmission(glass)
+        r.assume_compute_units(cus)
         r.upload_scene(scene)
         r.enable_validation(True)
         if seed_acc is not None:
