@@ -352,7 +352,7 @@ RTMI_API int rtmi_selftest_closest_hit(rtmi_ctx *ctx, uint32_t sphere_number, ui
 RTMI_API int rtmi_assume_compute_units(rtmi_ctx *ctx, int n);
 /* How RTMI_VARIANT_COMPACT deals its work list to waves on this context's device and image size when the list
  * holds n_listed pixels and the launch renders n_frames frames of rays_per_pixel samples of a scene with mesh_number
- * meshes (without a hierarchy): pixels per wave (64, 32, 16 or 8), and whether a wave's pixels are neighbours in the
+ * meshes (without a hierarchy): pixels per wave (64, 32, 16, 8 or 4), and whether a wave's pixels are neighbours in the
  * list (1) or spread evenly over it (0).  The same function the kernel evaluates.  The choice changes how the work
  * is spread, never a result; tests use this to know which form a configuration exercises.  No counterpart in the
  * reference (the shader's work groups are fixed, Raytracing.comp:89). */

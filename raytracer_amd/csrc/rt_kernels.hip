@@ -982,11 +982,11 @@ const char *RT_SYM(rt_kernel_name)(int variant)
 
 // Workgroups of a k_paths launch: one single-wave workgroup per 64 list entries at least; the list's length is
 // only known on the device, so the grid covers the worst case and surplus workgroups leave at once.  k_paths may
-// deal a short list out 32, 16 or 8 pixels to a wave: the grid allows for twice as many waves as 64 to a wave
-// need, eight times as many for images up to 2^20 pixels, where surplus workgroups cost next to nothing.
+// deal a short list out 32, 16, 8 or 4 pixels to a wave: the grid allows for twice as many waves as 64 to a wave
+// need, sixteen times as many for images up to 2^20 pixels, where surplus workgroups cost next to nothing.
 static uint32_t paths_grid(uint32_t n_pixels, bool bvh)
 {
-    const uint32_t per_group = bvh ? 64u : (n_pixels <= (1u << 20) ? 8u : 32u);
+    const uint32_t per_group = bvh ? 64u : (n_pixels <= (1u << 20) ? 4u : 32u);
     return (n_pixels + per_group - 1u) / per_group;
 }
 

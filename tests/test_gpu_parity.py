@@ -440,11 +440,11 @@ def test_waves_of_neighbouring_pixels(rtmi, oracle, size, n, want_deal, rows):
 
 
 @pytest.mark.parametrize("size,n,cus,want_deal", [((128, 72), 24, 1, (16, True)), ((128, 72), 32, 2, (8, True)),
-                                                  ((256, 144), 4, 1, (64, True)), ((256, 144), 8, 2, (32, True)),
+                                                  ((256, 144), 4, 1, (64, True)), ((256, 144), 8, 2, (32, True)), ((128, 72), 64, 4, (4, True)),
                                                   ((128, 72), 24, 64, (16, False)), ((128, 72), 24, 0, None)])
 def test_every_way_of_dealing_work_on_a_device_taken_to_be_small(rtmi, oracle, size, n, cus, want_deal):
     """rtmi_assume_compute_units makes the scheduling decisions for a device of that many compute units, so that a
-    small image goes through the forms that only large ones take on the real device: waves of 64, 32, 16 and 8
+    small image goes through the forms that only large ones take on the real device: waves of 64, 32, 16, 8 and 4
     neighbouring pixels, and the spread form.  Whole image, every output, against the oracle; the event counters
     against the one-lane-per-pixel kernel."""
     case = dict(scene="reference", pose=cases.BENCH_POSE, size=size, rpp=1, max_bounce=6, first=1, n=n)
