@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profile set (on the GPU box): bench lines of every workload (and of C2-C4 in the fused arithmetic profile, and of the C5 variant with transmitting materials), the default bench command under
+# Profile set (on the GPU box): bench lines of every workload (and of C2-C4 in the fused arithmetic profile, and of the C5 variant with transmitting materials), the default bench command under
 # rocprofv3 --kernel-trace --stats, kernel statistics of C3 / C4 (the bench's own launch sizes) / C5 / C1, lane
 # tallies of k_paths (sphere and mesh parts) and cycle stamps, the frame-loop rate at the reference's defaults.
 # Needs scratch/librtmi_prof.so, _prof2.so, _stamps.so from tools/build_variant.sh.  Results: gpurun_out/r03/.
