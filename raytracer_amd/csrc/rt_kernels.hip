@@ -990,9 +990,9 @@ static uint32_t paths_grid(uint32_t n_pixels, bool bvh)
     return (n_pixels + per_group - 1u) / per_group;
 }
 
-uint32_t RT_SYM(rt_paths_deal)(uint32_t n_pixels, uint32_t n_hit, uint32_t paths_per_pixel, uint32_t n_cus, bool meshes)
+uint32_t RT_SYM(rt_paths_deal)(uint32_t n_pixels, uint32_t n_hit, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t n_cus, bool meshes)
 {
-    return paths_deal(n_hit, paths_per_pixel, n_cus, paths_grid(n_pixels, false), meshes);
+    return paths_deal(n_hit, n_frames, rays_per_pixel, n_cus, paths_grid(n_pixels, false), meshes);
 }
 
 hipError_t RT_SYM(rt_launch_render)(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache)

@@ -54,7 +54,8 @@ enum RtCacheUse {
 #define RT_DECLARE_LAUNCHERS(S)                                                                                                       \
     const char *rt_kernel_name##S(int variant);                                                                                       \
     hipError_t rt_launch_render##S(int variant, bool validate, const RenderParams &p, hipStream_t stream, RtCacheUse cache);          \
-    uint32_t rt_paths_deal##S(uint32_t n_pixels, uint32_t n_hit, uint32_t paths_per_pixel, uint32_t n_cus, bool meshes);              \
+    uint32_t rt_paths_deal##S(uint32_t n_pixels, uint32_t n_hit, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t n_cus,          \
+                              bool meshes);                                                                                          \
     hipError_t rt_launch_resolve##S(float4 *accum, uint32_t *out, uint32_t n_pixels, float divisor, hipStream_t stream);              \
     hipError_t rt_launch_selftest_hit##S(const rtd::DeviceScene &sc, bool use_bvh, uint32_t n_spheres, uint32_t n_meshes,             \
                                          const float *origins, const float *dirs, size_t n, float *t_out, uint32_t *prim_out,         \

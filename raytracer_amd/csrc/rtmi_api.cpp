@@ -804,7 +804,7 @@ int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames
 {
     if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL context");
     if (!pixels_out || !neighbours_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
-    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames * rays_per_pixel,
+    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames, rays_per_pixel,
                                         (uint32_t)(c->assumed_cus > 0 ? c->assumed_cus : c->n_cus), mesh_number != 0u);
     *pixels_out = 1u << (deal & 255u);
     *neighbours_out = (deal & 256u) != 0u;
