@@ -17,13 +17,18 @@ def _same(a, b):
     return cases.bits_equal(a.read_accum(), b.read_accum()) and np.array_equal(a.read_output_rgba8(), b.read_output_rgba8())
 
 
-def test_store_use_and_invalidation(rtmi):
-    w, h = 96, 54
+@pytest.mark.parametrize("w,h,cus", [(96, 54, 0), (192, 108, 1)])
+def test_store_use_and_invalidation(rtmi, w, h, cus):
+    """cus = 1: the scheduling decisions are made for a device of one compute unit, so that the launches of the
+    compacting pair that start from the store take waves of neighbouring pixels, as large images do on the real device."""
     ref, sph = rtmi.reference_scene(), rtmi.sphere_scene()
     auto, plain = _both(rtmi, w, h)
     with auto, plain:
         for r in (auto, plain):
+            r.assume_compute_units(cus)
             r.upload_scene(ref)
+        if cus:
+            assert auto.paths_pixels_per_wave(w * h // 4, 20, 2, 2)[1] is True
         fd = rtmi.make_frame_data(w, h, ref, rtmi.BENCH_POSE, rays_per_pixel=2, max_bounce=6)
         frame = 0
 
