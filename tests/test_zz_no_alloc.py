@@ -12,7 +12,7 @@ import cases
 pytestmark = pytest.mark.gpu
 
 
-def _pair(rtmi, case, variant, accel=None, scene=None, fd=None):
+def _pair(rtmi, case, variant, accel=None, scene=None, fd=None, cus=0):
     """(image, display) of the plain entry point and of the no-allocation one, same inputs."""
     sc = scene if scene is not None else cases.product_scene(case)
     fd = fd if fd is not None else cases.product_frame_data(case, sc)
@@ -22,6 +22,7 @@ def _pair(rtmi, case, variant, accel=None, scene=None, fd=None):
         with rtmi.Renderer(w, h, variant=variant) as r:
             if accel is not None:
                 r.set_acceleration(accel)
+            r.assume_compute_units(cus)
             r.upload_scene(sc)
             if case.get("seed_accum"):
                 r.write_accum(cases.seed_accum(case))
@@ -42,6 +43,22 @@ def test_two_calls_in_a_row_second_one_smaller(rtmi, variant):
     # the small case is also a golden fixture's scene: the plain entry point is itself pinned to the oracle
     case = cases.CASES["c3_mesh_bench_pose"]
     (want, want8), (got, got8) = _pair(rtmi, case, variant)
+    gold = cases.load_golden("c3_mesh_bench_pose")
+    assert cases.bits_equal(got, gold["accum"]) and np.array_equal(got8, gold["rgba8"])
+
+
+def test_waves_of_neighbouring_pixels(rtmi):
+    """Scheduling decisions as for a device of one compute unit: the mesh scene's work list then goes to waves of
+    neighbouring pixels, as a large image's does on the real device; same bits from both entry points, and the
+    golden fixture's bits."""
+    case = dict(cases.CASES["c3_mesh_bench_pose"], size=(192, 108), n=24)
+    with rtmi.Renderer(192, 108) as r:
+        r.assume_compute_units(1)
+        assert r.paths_pixels_per_wave(192 * 108 // 4, 24, case["rpp"], 2)[1] is True
+    (want, want8), (got, got8) = _pair(rtmi, case, 2, cus=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got8, want8)
+    case = cases.CASES["c3_mesh_bench_pose"]
+    (want, want8), (got, got8) = _pair(rtmi, case, 2, cus=1)
     gold = cases.load_golden("c3_mesh_bench_pose")
     assert cases.bits_equal(got, gold["accum"]) and np.array_equal(got8, gold["rgba8"])
 
