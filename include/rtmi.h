@@ -358,6 +358,11 @@ RTMI_API int rtmi_assume_compute_units(rtmi_ctx *ctx, int n);
  * reference (the shader's work groups are fixed, Raytracing.comp:89). */
 RTMI_API int rtmi_paths_pixels_per_wave(rtmi_ctx *ctx, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel,
                                         uint32_t mesh_number, uint32_t *pixels_out, int *neighbours_out);
+/* The same function for a given image size and number of compute units, without a context or a device (host logic:
+ * what the CPU-only tests check the dealing rules with). */
+RTMI_API int rtmi_paths_pixels_per_wave_for(uint32_t width, uint32_t height, uint32_t compute_units, uint32_t n_listed,
+                                            uint32_t n_frames, uint32_t rays_per_pixel, uint32_t mesh_number,
+                                            uint32_t *pixels_out, int *neighbours_out);
 /* The same question, for a scene with a hierarchy, answered by a kernel that does nothing but walk: persistent
  * waves whose lanes take ray after ray (in the order given) and resume their walks as the path kernels do.  Same
  * results; *ms_out receives the shortest of `repeats` launches.  A measurement hook: what the walks of a set of

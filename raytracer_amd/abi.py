@@ -145,6 +145,8 @@ PROTOTYPES = {
     "rtmi_selftest_env_light": (C.c_int, [_ctx, C.POINTER(FrameData), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rtmi_selftest_exhaustive": (C.c_int, [_ctx, C.c_int, C.c_float, C.c_void_p]),
     "rtmi_assume_compute_units": (C.c_int, [_ctx, C.c_int]),
+    "rtmi_paths_pixels_per_wave_for": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "rtmi_paths_pixels_per_wave": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "rtmi_selftest_walk": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_float)]),

@@ -799,16 +799,25 @@ int rtmi_assume_compute_units(rtmi_ctx *c, int n)
     return RTMI_OK;
 }
 
+int rtmi_paths_pixels_per_wave_for(uint32_t width, uint32_t height, uint32_t compute_units, uint32_t n_listed, uint32_t n_frames,
+                                   uint32_t rays_per_pixel, uint32_t mesh_number, uint32_t *pixels_out, int *neighbours_out)
+{
+    if (!pixels_out || !neighbours_out) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave_for: NULL argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0xFFFFFFFFull || n_listed > (uint64_t)width * height)
+        return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave_for: %u listed pixels of a %u x %u image", n_listed, width, height);
+    const uint32_t deal = rt_paths_deal(width * height, n_listed, n_frames, rays_per_pixel, compute_units, mesh_number != 0u);
+    *pixels_out = 1u << (deal & 255u);
+    *neighbours_out = (deal & 256u) != 0u;
+    return RTMI_OK;
+}
+
 int rtmi_paths_pixels_per_wave(rtmi_ctx *c, uint32_t n_listed, uint32_t n_frames, uint32_t rays_per_pixel, uint32_t mesh_number,
                                uint32_t *pixels_out, int *neighbours_out)
 {
     if (!c) return fail(nullptr, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL context");
-    if (!pixels_out || !neighbours_out) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_paths_pixels_per_wave: NULL argument");
-    const uint32_t deal = rt_paths_deal((uint32_t)n_pixels(c), n_listed, n_frames, rays_per_pixel,
-                                        (uint32_t)(c->assumed_cus > 0 ? c->assumed_cus : c->n_cus), mesh_number != 0u);
-    *pixels_out = 1u << (deal & 255u);
-    *neighbours_out = (deal & 256u) != 0u;
-    return RTMI_OK;
+    const int rc = rtmi_paths_pixels_per_wave_for(c->width, c->height, (uint32_t)(c->assumed_cus > 0 ? c->assumed_cus : c->n_cus), n_listed,
+                                                  n_frames, rays_per_pixel, mesh_number, pixels_out, neighbours_out);
+    return rc == RTMI_OK ? rc : fail(c, rc, "%s", rtmi_last_error(nullptr));
 }
 
 int rtmi_device_count(void)
