@@ -305,47 +305,3 @@ def test_scene_file_is_readable_text_and_rejects_damage(rtmi, tmp_path):
     with pytest.raises(rtmi.RtmiError):
         rtmi.Scene.load(tmp_path / "missing.txt")
 
-
-def test_how_the_work_list_is_dealt_to_waves(rtmi):
-    """The dealing rules of the compacting pair (rtmi_paths_pixels_per_wave_for: the function the kernel evaluates,
-    here on the host without a device), for a device of 256 compute units at the sizes the measurements were made
-    at: (pixels per wave, neighbouring pixels?)."""
-    lib = rtmi.abi.load()
-
-    def deal(w, h, n_listed, n_frames, rpp=1, meshes=0, cus=256):
-        px, nb = C.c_uint32(0), C.c_int(0)
-        assert lib.rtmi_paths_pixels_per_wave_for(w, h, cus, n_listed, n_frames, rpp, meshes, C.byref(px), C.byref(nb)) == 0
-        return int(px.value), bool(nb.value)
-
-    # the spheres scene at 1080p lists 2 M pixels: 64 to a wave, spread, at every launch length
-    for n in (1, 2, 8, 64, 256):
-        assert deal(1920, 1080, 2070000, n) == (64, False)
-    # the reference scene at 1080p lists 0.56 M: 16 neighbours from 16 frames on, spread below
-    assert deal(1920, 1080, 560000, 256, meshes=2) == (16, True)
-    assert deal(1920, 1080, 560000, 16, meshes=2) == (16, True)
-    assert deal(1920, 1080, 560000, 8, meshes=2) == (64, False)
-    assert deal(1920, 1080, 560000, 2, meshes=2) == (64, False)
-    # without meshes the same list is spread, with the fitted count
-    assert deal(1920, 1080, 560000, 256) == (16, False)
-    assert deal(1920, 1080, 560000, 32) in ((32, False), (64, False))
-    assert deal(1920, 1080, 560000, 2) == (64, False)
-    # 3840 x 2160: 2.24 M listed
-    assert deal(3840, 2160, 2240000, 512, meshes=2) == (16, True)
-    assert deal(3840, 2160, 2240000, 8, meshes=2) == (32, True)
-    assert deal(3840, 2160, 2240000, 2, meshes=2) == (64, True)
-    # one frame of many samples is still one item per pixel: a wave needs 64 of them
-    assert deal(3840, 2160, 2240000, 1, rpp=16, meshes=2) == (64, True)
-    assert deal(3840, 2160, 2240000, 2, rpp=8, meshes=2) == (32, True)
-    # shorter lists: 8 neighbours at 1280 x 720 (0.25 M listed), 4 at 960 x 540 (0.14 M), spread at 640 x 360 (65 k)
-    assert deal(1280, 720, 250000, 256, meshes=2) == (8, True)
-    assert deal(1280, 720, 250000, 16, meshes=2)[1] is False
-    assert deal(960, 540, 140000, 256, meshes=2) == (4, True)
-    assert deal(640, 360, 65000, 64, meshes=2) == (16, False)
-    assert deal(640, 360, 65000, 2, meshes=2) == (32, False)
-    # a smaller device takes neighbours sooner
-    assert deal(640, 360, 65000, 64, meshes=2, cus=32) == (16, True)
-    # bad arguments
-    px, nb = C.c_uint32(0), C.c_int(0)
-    assert lib.rtmi_paths_pixels_per_wave_for(0, 360, 256, 1, 1, 1, 0, C.byref(px), C.byref(nb)) != 0
-    assert lib.rtmi_paths_pixels_per_wave_for(64, 36, 256, 64 * 36 + 1, 1, 1, 0, C.byref(px), C.byref(nb)) != 0
-    assert lib.rtmi_paths_pixels_per_wave_for(64, 36, 256, 10, 1, 1, 0, None, C.byref(nb)) != 0
