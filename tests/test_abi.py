@@ -79,10 +79,11 @@ def test_how_the_work_list_is_dealt_to_waves(rtmi):
     # the spheres scene at 1080p lists 2 M pixels: 64 to a wave, spread, at every launch length
     for n in (1, 2, 8, 64, 256):
         assert deal(1920, 1080, 2070000, n) == (64, False)
-    # the reference scene at 1080p lists 0.56 M: 16 neighbours from 16 frames on, spread below
+    # the reference scene at 1080p lists 0.56 M: 16 neighbours from 16 frames on (5.7 rounds of wave slots), 32 over 8
+    # frames (2.8 rounds: the fewest pixels that leave four paths per lane), spread below
     assert deal(1920, 1080, 560000, 256, meshes=2) == (16, True)
     assert deal(1920, 1080, 560000, 16, meshes=2) == (16, True)
-    assert deal(1920, 1080, 560000, 8, meshes=2) == (64, False)
+    assert deal(1920, 1080, 560000, 8, meshes=2) == (32, True)
     assert deal(1920, 1080, 560000, 2, meshes=2) == (64, False)
     # without meshes the same list is spread, with the fitted count
     assert deal(1920, 1080, 560000, 256) == (16, False)
@@ -95,11 +96,15 @@ def test_how_the_work_list_is_dealt_to_waves(rtmi):
     # one frame of many samples is still one item per pixel: a wave needs 64 of them
     assert deal(3840, 2160, 2240000, 1, rpp=16, meshes=2) == (64, True)
     assert deal(3840, 2160, 2240000, 2, rpp=8, meshes=2) == (32, True)
-    # shorter lists: 8 neighbours at 1280 x 720 (0.25 M listed), 4 at 960 x 540 (0.14 M), spread at 640 x 360 (65 k)
+    # shorter lists: 8 neighbours at 1280 x 720 (0.25 M listed), 4 at 960 x 540 (0.14 M) and at 640 x 360 (65 k: 2.6
+    # rounds, nothing makes four); too few frames for that: spread
     assert deal(1280, 720, 250000, 256, meshes=2) == (8, True)
-    assert deal(1280, 720, 250000, 16, meshes=2)[1] is False
+    assert deal(1280, 720, 250000, 16, meshes=2) == (16, True)     # 2.5 rounds, and 8 to a wave would leave two paths per lane
+    assert deal(1280, 720, 230000, 16, meshes=2)[1] is False       # 2.3 rounds
     assert deal(960, 540, 140000, 256, meshes=2) == (4, True)
-    assert deal(640, 360, 65000, 64, meshes=2) == (16, False)
+    assert deal(640, 360, 65000, 64, meshes=2) == (4, True)
+    assert deal(640, 360, 65000, 64) == (16, False)
+    assert deal(640, 360, 50000, 64, meshes=2) == (16, False)      # 2 rounds at 4 to a wave
     assert deal(640, 360, 65000, 2, meshes=2) == (32, False)
     # a smaller device takes neighbours sooner
     assert deal(640, 360, 65000, 64, meshes=2, cus=32) == (16, True)
