@@ -76,9 +76,12 @@ def test_how_the_work_list_is_dealt_to_waves(rtmi):
         assert lib.rtmi_paths_pixels_per_wave_for(w, h, cus, n_listed, n_frames, rpp, meshes, C.byref(px), C.byref(nb)) == 0
         return int(px.value), bool(nb.value)
 
-    # the spheres scene at 1080p lists 2 M pixels: 64 to a wave, spread, at every launch length
-    for n in (1, 2, 8, 64, 256):
+    # the spheres scene at 1080p lists 2 M pixels: 64 to a wave, spread, at every launch length but one frame
+    for n in (2, 8, 64, 256):
         assert deal(1920, 1080, 2070000, n) == (64, False)
+    # a one-frame launch has one item per lane and nothing to refill from: waves of like pixels, whatever the scene
+    assert deal(1920, 1080, 2070000, 1) == (64, True)
+    assert deal(640, 360, 65000, 1, rpp=4, meshes=2) == (64, True)
     # the reference scene at 1080p lists 0.56 M: 16 neighbours from 16 frames on (5.7 rounds of wave slots), 32 over 8
     # frames (2.8 rounds: the fewest pixels that leave four paths per lane), spread below
     assert deal(1920, 1080, 560000, 256, meshes=2) == (16, True)

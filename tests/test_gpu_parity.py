@@ -398,14 +398,14 @@ def test_pixels_per_wave_by_list_length_and_frame_count(rtmi, oracle):
         osc = cases.oracle_scene(case)
         want = oracle.render(cases.oracle_frame_data(case, osc), osc, 1, n)
         assert_same({k: v for k, v in got.items() if k != "counters"}, want)
-    assert len(seen) >= 2 and (64, False) in seen, seen
+    assert len(seen) >= 2 and (64, True) in seen, seen     # one frame: one item per lane, waves of like pixels
     # 1080p: the spheres scene lists every pixel below the horizon and more (5.3 rounds of wave slots at 64 to a wave)
     assert _deal(rtmi, (1920, 1080), 2000000, 256) == (64, False)
     # the reference scene lists about 0.56 M pixels: 16 neighbours to a wave over 256 frames, 32 over 8, 64 spread ones over 2
     assert _deal(rtmi, (1920, 1080), 560000, 256, 2) == (16, True)
     assert _deal(rtmi, (1920, 1080), 560000, 8, 2) == (32, True)
     assert _deal(rtmi, (1920, 1080), 560000, 2, 2) == (64, False)
-    assert _deal(rtmi, (1920, 1080), 560000, 256, 0) == (16, False)   # the sphere-only kernel never takes neighbours
+    assert _deal(rtmi, (1920, 1080), 560000, 256, 0) == (16, False)   # without meshes: spread (neighbours only in one-frame launches)
 
 
 @pytest.mark.parametrize("size,n,want_deal,rows", [((3840, 2160), 8, (32, True), (0, 1100, 2159)),
