@@ -201,7 +201,8 @@ RTMI_API int rtmi_render(rtmi_ctx *ctx, const rtmi_frame_data *fd);
 /* Same result as calling rtmi_render n_frames times with frame_index = first_frame,
  * first_frame+1, ... and otherwise unchanged *fd (fd->frame_index itself is ignored), but in one
  * launch with the running sum kept in registers.  No counterpart call in the reference; it is the
- * reference frame loop (main.cpp:236-444) with a static camera. */
+ * reference frame loop (main.cpp:236-444) with a static camera.  At most 2^24 frames per call, and
+ * first_frame + n_frames - 1 must fit the shader's 32-bit frame index (RTMI_ERR_INVALID_ARGUMENT otherwise). */
 RTMI_API int rtmi_render_frames(rtmi_ctx *ctx, const rtmi_frame_data *fd,
                                 uint32_t first_frame, uint32_t n_frames);
 

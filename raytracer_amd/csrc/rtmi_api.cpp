@@ -355,6 +355,10 @@ static int render_impl(rtmi_ctx *c, const rtmi_frame_data *fd, uint32_t first_fr
     if (!fd) return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render: frame data is NULL");
     if (!c->has_scene) return fail(c, RTMI_ERR_NO_SCENE, "rtmi_render: no scene uploaded");
     if (n_frames == 0) return RTMI_OK;
+    // the kernels count items (frames x pixel slots of a wave) in 32 bits, and the shader's frame index has 32
+    if (n_frames > (1u << 24) || first_frame > 0xFFFFFFFFu - (n_frames - 1u))
+        return fail(c, RTMI_ERR_INVALID_ARGUMENT, "rtmi_render_frames: %u frames from frame %u on (at most 2^24 per call, frame index below 2^32)",
+                    n_frames, first_frame);
     if (fd->sphere_number > c->n_spheres || fd->mesh_number > c->n_meshes)
         return fail(c, RTMI_ERR_SCENE_MISMATCH, "rtmi_render: frame data names %u spheres / %u meshes, scene holds %u / %u",
                     fd->sphere_number, fd->mesh_number, c->n_spheres, c->n_meshes);

@@ -246,6 +246,11 @@ def test_error_paths(rtmi):
         with pytest.raises(rtmi.RtmiError) as e:
             r.upload_scene(bad)                   # mesh names triangles that do not exist
         assert e.value.code == a.ERR_INVALID_ARGUMENT
+        for first, n in ((1, (1 << 24) + 1), (0xFFFFFFFF, 2)):
+            with pytest.raises(rtmi.RtmiError) as e:
+                r.render_frames(fd, first, n)     # more frames than a call takes; frame index past 32 bits
+            assert e.value.code == a.ERR_INVALID_ARGUMENT
+        r.render_frames(fd, 0xFFFFFFFF, 1)        # the last frame index there is
         r.render_frames(fd, 1, 1)                 # the context is still usable
         r.synchronize()
     ctx = C.c_void_p()
